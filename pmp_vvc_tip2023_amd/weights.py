@@ -1,0 +1,91 @@
+"""Weight containers for the four Down-Up-CNN nets.
+
+The reference stores weights as legacy torch pickles with CUDA-tagged storages and DataParallel `module.`
+prefixes (trained_models/*.pkl; loader Inference_QBD.py:28-46).  The product's own container is `.pmpw`:
+
+    b"PMPW1\\n" | u32 little-endian JSON length | JSON manifest | raw little-endian float32 payload
+
+manifest = {"net": "Luma_Q", "qp": 22, "source": ..., "tensors": [{"name", "shape", "offset"(floats)}]}.
+Tensor names/shapes are the reference's state_dict names with `module.` stripped (OIHW convs, 1-D biases).
+`.pmpw` needs only numpy; `.pkl` import needs torch (PyTorch is used for weight loading only).
+"""
+import json
+import os
+import struct
+
+import numpy as np
+
+MAGIC = b"PMPW1\n"
+NETS = ("Luma_Q", "Luma_MSBD", "Chroma_Q", "Chroma_MSBD")
+QPS = (22, 27, 32, 37)
+
+
+def save_pmpw(path, net, qp, tensors, source=""):
+    """tensors: ordered {name: float32 ndarray}."""
+    entries, off = [], 0
+    for name, a in tensors.items():
+        a = np.ascontiguousarray(a, dtype="<f4")
+        entries.append({"name": name, "shape": list(a.shape), "offset": off})
+        off += a.size
+    man = json.dumps({"net": net, "qp": int(qp), "source": source, "tensors": entries}).encode()
+    with open(path, "wb") as f:
+        f.write(MAGIC)
+        f.write(struct.pack("<I", len(man)))
+        f.write(man)
+        for a in tensors.values():
+            f.write(np.ascontiguousarray(a, dtype="<f4").tobytes())
+
+
+def load_pmpw(path):
+    """-> (manifest dict, {name: float32 ndarray})."""
+    with open(path, "rb") as f:
+        if f.read(len(MAGIC)) != MAGIC:
+            raise ValueError("%s: not a PMPW1 file" % path)
+        (n,) = struct.unpack("<I", f.read(4))
+        man = json.loads(f.read(n).decode())
+        payload = np.frombuffer(f.read(), dtype="<f4")
+    out = {}
+    for e in man["tensors"]:
+        cnt = int(np.prod(e["shape"])) if e["shape"] else 1
+        out[e["name"]] = payload[e["offset"]:e["offset"] + cnt].reshape(e["shape"]).astype(np.float32)
+    return man, out
+
+
+def load_pkl(path):
+    """Reference pickle -> {name: float32 ndarray}; mirrors remove_prefix/load_pretrain_model
+    (Inference_QBD.py:28-46) but with map_location='cpu' (the shipped loader fails on CPU-only hosts)."""
+    import torch
+    sd = torch.load(path, map_location="cpu", weights_only=False)
+    if "state_dict" in sd:
+        sd = sd["state_dict"]
+    return {(k.split("module.", 1)[-1] if k.startswith("module.") else k):
+            v.detach().float().contiguous().numpy() for k, v in sd.items()}
+
+
+def default_weight_dir():
+    return os.environ.get("PMP_WEIGHT_DIR",
+                          os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "weights"))
+
+
+def ref_net_name(net):
+    """Our net id -> the reference's file stem: Luma_Q -> Luma_Q, Luma_MSBD -> Luma_BD (trained_models/README.md)."""
+    comp, kind = net.split("_", 1)
+    return comp + ("_Q" if kind == "Q" else "_BD")
+
+
+def load_net_weights(net, qp, weight_dir=None, allow_synthetic=True):
+    """Resolution order: <dir>/<Comp>_{Q,BD}_<qp>.pmpw, then .pkl (reference naming, Inference_QBD.py:219-220),
+    then - for the MTT nets only, whose files are absent from the reference mount - the documented
+    synthetic generator (seed = qp).  Returns (weights, provenance-string)."""
+    d = weight_dir or default_weight_dir()
+    stem = "%s_%d" % (ref_net_name(net), qp)
+    p = os.path.join(d, stem + ".pmpw")
+    if os.path.isfile(p):
+        return load_pmpw(p)[1], p
+    p = os.path.join(d, stem + ".pkl")
+    if os.path.isfile(p):
+        return load_pkl(p), p
+    if net.endswith("_MSBD") and allow_synthetic:
+        from . import synth
+        return synth.synth_msbd_weights(net.split("_")[0], qp), "synthetic(seed=%d)" % qp
+    raise FileNotFoundError("no weights for %s qp%d under %s" % (net, qp, d))

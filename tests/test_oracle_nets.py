@@ -1,0 +1,74 @@
+"""CPU: the oracle's torch restatement of the four nets against golden vectors produced by the imported
+reference modules (tools/gen_golden.py).  Tolerance 1e-4 (same arithmetic library, different call graph);
+the product's tolerance against these same vectors is north_star's 1e-3."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from oracle import nets_torch as O
+from pmp_vvc_tip2023_amd import synth, weights as W
+
+TOL = 1e-4
+
+
+@pytest.mark.parametrize("comp", ["Luma", "Chroma"])
+@pytest.mark.parametrize("qp", [22, 27, 32, 37])
+def test_q_net_real_weights(comp, qp):
+    g = golden("g1_qt.npz")
+    luma = comp == "Luma"
+    x = O.luma_input(g["block_y"]) if luma else O.chroma_input(g["block_y"], g["block_u"], g["block_v"])
+    wq, src = W.load_net_weights(comp + "_Q", qp)
+    assert src.endswith(".pmpw")
+    with torch.no_grad():
+        q = O.q_forward(wq, x, luma).numpy()
+    assert q.shape == (16, 1, 8, 8)
+    assert np.abs(q - g["qt_%s_%d" % (comp, qp)]).max() < TOL
+
+
+@pytest.mark.parametrize("comp", ["Luma", "Chroma"])
+@pytest.mark.parametrize("qp", [22, 37])
+def test_msbd_net_synth_weights(comp, qp):
+    g1, g2 = golden("g1_qt.npz"), golden("g2_msbd.npz")
+    luma = comp == "Luma"
+    x = (O.luma_input(g1["block_y"]) if luma else O.chroma_input(g1["block_y"], g1["block_u"], g1["block_v"]))[:8]
+    q = torch.from_numpy(g1["qt_%s_%d" % (comp, qp)][:8])
+    wbd = synth.synth_msbd_weights(comp, qp)
+    taps = {}
+    with torch.no_grad():
+        o = O.msbd_forward(wbd, x, q, luma, taps=taps)
+    for i in range(3):
+        assert np.abs(o[i].numpy() - g2["out%d_%s_%d" % (i, comp, qp)]).max() < TOL
+    if qp == 22:
+        # in-place accumulation order (Model_QBD.py:146-147): out1.ch0 = raw + out0.ch0, ch1 untouched
+        raw = taps["out1_raw"].numpy()
+        assert np.abs(raw[:2] - g2["out1_raw_%s" % comp]).max() < TOL
+        assert np.allclose(o[1].numpy()[:, 0], raw[:, 0] + o[0].numpy()[:, 0], atol=1e-6)
+        assert np.array_equal(o[1].numpy()[:, 1], raw[:, 1])
+
+
+@pytest.mark.parametrize("comp", ["Luma", "Chroma"])
+def test_infer_qbd_regrouping(comp):
+    """Metrics.py:399-402: bt = ch0 of the three heads, dire = ch1."""
+    g1, g2 = golden("g1_qt.npz"), golden("g2_msbd.npz")
+    luma = comp == "Luma"
+    x = (O.luma_input(g1["block_y"]) if luma else O.chroma_input(g1["block_y"], g1["block_u"], g1["block_v"]))[:8]
+    wq, _ = W.load_net_weights(comp + "_Q", 22)
+    wbd = synth.synth_msbd_weights(comp, 22)
+    qt, bt, dire = O.infer_qbd(wq, wbd, x, luma, batch=3)   # ragged batches: 3+3+2
+    assert np.abs(qt - g2["pre_qt_%s" % comp]).max() < TOL
+    assert np.abs(bt - g2["pre_bt_%s" % comp]).max() < TOL
+    assert np.abs(dire - g2["pre_dire_%s" % comp]).max() < TOL
+
+
+def test_synth_weights_are_deterministic_and_complete():
+    for comp in ("Luma", "Chroma"):
+        a = synth.synth_msbd_weights(comp, 22)
+        b = synth.synth_msbd_weights(comp, 22)
+        assert len(a) == 72
+        assert all(np.array_equal(a[k], b[k]) for k in a)
+        n = sum(v.size for v in a.values())
+        assert n == (1075670 if comp == "Luma" else 1074198)   # SURVEY.md A.2 parameter counts
+    # PRNG known answers (SplitMix64 reference values for seed 0)
+    z = synth.splitmix64(0, 3)
+    assert [int(v) for v in z] == [0xE220A8397B1DCDAF, 0x6E789E6AA1B965F4, 0x06C45D188009454F]

@@ -1,0 +1,80 @@
+"""CPU: the oracle's C restatement of the integer side (cutter, eli fix, Map_to_Partition, writer) against
+golden vectors produced by the imported reference (tools/gen_golden.py) — bit-exact."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import g3_sets, golden, golden_path
+
+
+def test_map_to_partition_bit_exact(oracle_lib):
+    total = 0
+    for tag, cf, qt, bt, dire, hor, ver, dout, leaves in g3_sets():
+        h, v, d, lv = oracle_lib.map_to_partition(qt, bt, dire, cf)
+        assert np.array_equal(h, hor), (tag, cf)
+        assert np.array_equal(v, ver), (tag, cf)
+        assert np.array_equal(d, dout), (tag, cf)
+        assert np.array_equal(lv, leaves), (tag, cf)
+        total += len(qt)
+    assert total >= 1000
+
+
+def test_eli_structural_error_bit_exact(oracle_lib):
+    g = golden("g4_eli.npz")
+    out = oracle_lib.eli_structural_error(g["qt"])
+    assert np.array_equal(out, g["out"].astype(np.float32))
+    # invariants of Metrics.py:612-628: 2x2-constant, values 0..3
+    o = out.reshape(-1, 8, 8)
+    assert np.array_equal(o[:, ::2, ::2], o[:, 1::2, 1::2]) and o.min() >= 0 and o.max() <= 3
+
+
+@pytest.mark.parametrize("comp", ["Luma", "Chroma"])
+def test_sequence_file_bytes(oracle_lib, comp, tmp_path):
+    g = golden("g5_seq_%s.npz" % comp)
+    p = str(tmp_path / "o.txt")
+    oracle_lib.seq_post_process(g["qt"], g["bt"], g["dire"], comp, int(g["F"]), int(g["W"]), int(g["H"]), p)
+    data = open(p, "rb").read()
+    assert hashlib.sha256(data).hexdigest() == str(g["sha256"])
+    assert data == open(golden_path("g5_partitionmat_%s.txt" % comp), "rb").read()
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_block_cutter(oracle_lib, bd):
+    g = golden("g6_cut.npz")
+    by, bu, bv = oracle_lib.cut_blocks(g["y%d" % bd], g["u%d" % bd], g["v%d" % bd], bd)
+    assert np.array_equal(by, g["by%d" % bd]) and np.array_equal(bu, g["bu%d" % bd]) and np.array_equal(bv, g["bv%d" % bd])
+    assert by.shape == (3 * 1 * 2, 68, 68)      # 136x72 -> 2x1 blocks per frame, remainder dropped
+
+
+def test_real_partitionmat_fixture_invariants():
+    """G7: first frame of the reference's own demo output (RaceHorses 416x240 Luma QP22): format invariants
+     that the product's writer/post-processing must also satisfy."""
+    vals = np.array(open(golden_path("g7_racehorses_luma_qp22_frame0.txt")).read().split(), dtype=np.int64)
+    R, C = 48, 96
+    assert vals.size == 5 * R * C + R * C // 4
+    hor = vals[:R * C].reshape(R, C); ver = vals[R * C:2 * R * C].reshape(R, C)
+    qt = vals[2 * R * C:2 * R * C + R * C // 4].reshape(R // 2, C // 2)
+    dire = vals[2 * R * C + R * C // 4:].reshape(3, R, C)
+    assert set(np.unique(hor)) <= {0, 1} and set(np.unique(ver)) <= {0, 1}
+    assert qt.min() >= 0 and qt.max() <= 3 and dire.min() >= -1 and dire.max() <= 1
+    assert hor[::16].all() and ver[:, ::16].all()                  # block top rows / left columns are edges
+    assert np.array_equal(qt[::2, ::2], qt[1::2, 1::2])            # QT section is 2x2-constant
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="live reference only exists in the build container")
+def test_oracle_against_live_reference(oracle_lib):
+    """Fresh random maps through the imported reference (not a committed fixture)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import ref_harness as R
+    from pmp_vvc_tip2023_amd import synth
+    _, _, M2P, _ = R.load()
+    seed = int.from_bytes(os.urandom(2), "little")
+    for cf in (1, 2):
+        qt, bt, dire = synth.random_partition_batch(40, seed + cf, cf, 0.25)
+        h, v, d, _ = oracle_lib.map_to_partition(qt, bt, dire, cf)
+        for i in range(len(qt)):
+            rh, rv, rd = M2P.map_to_parititon(qt[i], bt[i], dire[i], cf)
+            assert np.array_equal(rh, h[i]) and np.array_equal(rv, v[i]) and np.array_equal(rd, d[i]), (seed, cf, i)
