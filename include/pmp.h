@@ -1,0 +1,130 @@
+/*
+ * pmp.h — C ABI of libpmp_hip.so: the MI355X (gfx950) partition-map prediction path.
+ *
+ * The reference (AolinFeng/PMP-VVC-TIP2023) has no FFI; its hot path is plain Python.  This ABI replaces the
+ * two function seams of that path and the helpers either side of them:
+ *
+ *   pmp_infer*              <- Metrics.py:387-419   inference_pre_QBD  (Net_Q + Net_BD forward, head regrouping)
+ *                              Model_QBD.py:59-253  the four Down-Up-CNN nets
+ *                              Inference_QBD.py:194-200 driver tensor prep (chroma = maxpool2(Y) ++ U ++ V)
+ *   pmp_postprocess*        <- Metrics.py:764-774   seq_post_process   = eli_structual_error (Metrics.py:612-637)
+ *                              + Map2Partition.py:98-373 Map_to_Partition (per-block search)
+ *   pmp_infer_postprocess*  <- both, device-resident (no logits round trip): the throughput path
+ *   pmp_cut_blocks*         <- Inference_QBD.py:104-149 output_block_yuv (+ :106-109 10-bit -> 8-bit)
+ *   pmp_write_partition_file<- Map2Partition.py:385-412 frame tiling + text emission, parsed by
+ *                              EncAppCfg::parsePartitionMatrix (codec/.../App/EncoderApp/EncAppCfg.cpp:4234-4404)
+ *   pmp_load_weights        <- Inference_QBD.py:28-46 load_pretrain_model (state_dict tensors by name)
+ *
+ * Conventions
+ *   - Every call returns 0 (PMP_OK) or a negative error class; pmp_last_error() gives the message.  Nothing
+ *     aborts or throws across the ABI; HIP errors are mapped to PMP_E_HIP.
+ *   - One context per GPU.  A context is not thread-safe; different contexts are independent.
+ *   - There is NO CPU fallback: every compute entry point needs a context on a gfx950 device.
+ *   - "block" = one 64x64 luma region with its 4-pixel top/left context: u8[68][68] luma, u8[34][34] per chroma
+ *     plane (Inference_QBD.py:190-191).  One VTM CTU (128x128) = 4 blocks.
+ *   - Layouts (all dense, row-major):  qt f32[n][8][8]; bt, dire f32[n][3][16][16] (layer-major, as
+ *     Metrics.py:399-402 regroups the heads); hor, ver u8[n][16][16]; qt_u8 u8[n][8][8]; dire_i8 i8[n][3][16][16].
+ *   - *_device variants take device pointers and run asynchronously on the context's stream
+ *     (pmp_set_stream lets the caller supply it); the others take host pointers and synchronise.
+ */
+#ifndef PMP_H
+#define PMP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMP_OK 0
+#define PMP_E_INVALID (-1)   /* bad argument / unknown net / shape mismatch */
+#define PMP_E_HIP (-2)       /* HIP runtime error (message has hipGetErrorString) */
+#define PMP_E_NOWEIGHTS (-3) /* weights for (comp, qp) not loaded */
+#define PMP_E_IO (-4)        /* file could not be written */
+#define PMP_E_NOMEM (-5)     /* device or host allocation failed */
+#define PMP_E_NODEVICE (-6)  /* no gfx950 device: there is no CPU fallback */
+
+enum { PMP_LUMA = 0, PMP_CHROMA = 1 };
+enum { PMP_NET_LUMA_Q = 0, PMP_NET_LUMA_MSBD = 1, PMP_NET_CHROMA_Q = 2, PMP_NET_CHROMA_MSBD = 3 };
+
+typedef struct pmp_ctx pmp_ctx;
+
+/* One state_dict entry (name without the DataParallel "module." prefix, Inference_QBD.py:23-25). */
+typedef struct {
+    const char *name;  /* e.g. "resblock_q1.left.0.weight" */
+    int ndim;          /* 4 (OIHW conv weight) or 1 (bias) */
+    int shape[4];
+    int64_t offset;    /* in floats, into the blob */
+} pmp_tensor_desc;
+
+const char *pmp_version(void);
+
+/* pmp_last_error(NULL) returns the calling thread's last context-less error (e.g. from pmp_create). */
+const char *pmp_last_error(const pmp_ctx *ctx);
+
+int pmp_create(int device_id, pmp_ctx **out);
+int pmp_destroy(pmp_ctx *ctx);
+
+/* Use the caller's hipStream_t (e.g. torch's current stream); NULL restores the context's own stream. */
+int pmp_set_stream(pmp_ctx *ctx, void *hip_stream);
+int pmp_synchronize(pmp_ctx *ctx);
+
+/* Blocks processed per pass (activation workspace is sized for it); n > chunk is looped.  Default 512. */
+int pmp_set_chunk(pmp_ctx *ctx, int blocks);
+
+/* Caller keeps ownership of blob/descs; the library re-packs into its kernel layouts in device memory.
+ * Every tensor the net needs must be present with the reference's shape (else PMP_E_INVALID). */
+int pmp_load_weights(pmp_ctx *ctx, int net_id, int qp, const float *blob, const pmp_tensor_desc *descs,
+                     int ndesc);
+int pmp_has_weights(const pmp_ctx *ctx, int net_id, int qp);
+
+/* ---- inference: inference_pre_QBD (Metrics.py:387-419).  block_u/block_v are ignored for PMP_LUMA. --- */
+int pmp_infer(pmp_ctx *ctx, int comp, int qp, const uint8_t *block_y, const uint8_t *block_u,
+              const uint8_t *block_v, int64_t n, float *qt, float *bt, float *dire);
+int pmp_infer_device(pmp_ctx *ctx, int comp, int qp, const uint8_t *d_block_y, const uint8_t *d_block_u,
+                     const uint8_t *d_block_v, int64_t n, float *d_qt, float *d_bt, float *d_dire);
+
+/* ---- post-processing: seq_post_process minus the file (Metrics.py:764-774).  qt = RAW QT logits. ------- */
+int pmp_postprocess(pmp_ctx *ctx, int comp, const float *qt, const float *bt, const float *dire, int64_t n,
+                    uint8_t *hor, uint8_t *ver, uint8_t *qt_u8, int8_t *dire_i8);
+int pmp_postprocess_device(pmp_ctx *ctx, int comp, const float *d_qt, const float *d_bt, const float *d_dire,
+                           int64_t n, uint8_t *d_hor, uint8_t *d_ver, uint8_t *d_qt_u8, int8_t *d_dire_i8);
+
+/* ---- fused: blocks in, split flags out; logits stay in HBM (qt/bt/dire may be NULL). ------------------- */
+int pmp_infer_postprocess(pmp_ctx *ctx, int comp, int qp, const uint8_t *block_y, const uint8_t *block_u,
+                          const uint8_t *block_v, int64_t n, uint8_t *hor, uint8_t *ver, uint8_t *qt_u8,
+                          int8_t *dire_i8, float *qt, float *bt, float *dire);
+int pmp_infer_postprocess_device(pmp_ctx *ctx, int comp, int qp, const uint8_t *d_block_y,
+                                 const uint8_t *d_block_u, const uint8_t *d_block_v, int64_t n, uint8_t *d_hor,
+                                 uint8_t *d_ver, uint8_t *d_qt_u8, int8_t *d_dire_i8, float *d_qt, float *d_bt,
+                                 float *d_dire);
+
+/* ---- block cutter: output_block_yuv (Inference_QBD.py:104-149).  Planes y[F][H][W], u,v[F][H/2][W/2];
+ *      bitdepth 8 -> uint8 samples, 10 -> uint16 samples reduced with round-half-even(x/4), clipped to 255.
+ *      Writes F*(H/64)*(W/64) blocks, frame-major then row-major; right/bottom remainders are dropped. ---- */
+int pmp_cut_blocks(pmp_ctx *ctx, const void *y, const void *u, const void *v, int frames, int height, int width,
+                   int bitdepth, uint8_t *block_y, uint8_t *block_u, uint8_t *block_v);
+int pmp_cut_blocks_device(pmp_ctx *ctx, const void *d_y, const void *d_u, const void *d_v, int frames,
+                          int height, int width, int bitdepth, uint8_t *d_block_y, uint8_t *d_block_u,
+                          uint8_t *d_block_v);
+
+/* ---- PartitionMat text file (Map2Partition.py:385-412): per frame hor, ver, qt, dire[3]; one decimal
+ *      integer per line.  Host-side (file I/O); inputs are per-block arrays in block order. ---------------- */
+int pmp_write_partition_file(const char *path, int frames, int height, int width, const uint8_t *hor,
+                             const uint8_t *ver, const uint8_t *qt_u8, const int8_t *dire_i8);
+/* Same bytes into memory: returns the byte count (or a negative error); buf may be NULL to size it. */
+int64_t pmp_format_partition_text(int frames, int height, int width, const uint8_t *hor, const uint8_t *ver,
+                                  const uint8_t *qt_u8, const int8_t *dire_i8, char *buf, int64_t cap);
+
+/* ---- per-kernel-class timing with hipEvents on the launch stream (bench.py roofline leg). -------------- */
+/* mask: bit i enables kernel class i (see pmp_ktime_name); 0 disables.  Resets the accumulators. */
+int pmp_ktime_enable(pmp_ctx *ctx, uint32_t mask);
+int pmp_ktime_classes(void);
+const char *pmp_ktime_name(int cls);
+/* Synchronises, then returns launches / total milliseconds / algorithmic FLOPs accumulated for the class. */
+int pmp_ktime_get(pmp_ctx *ctx, int cls, int64_t *launches, double *ms, double *flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PMP_H */

@@ -1,0 +1,75 @@
+"""ctypes binding of libpmp_hip.so (C ABI: include/pmp.h).  No torch types cross this boundary: only raw
+pointers and sizes.  The library is built in-tree by `make -C pmp_vvc_tip2023_amd/csrc` (see __graft_entry__.build)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpmp_hip.so")
+
+PMP_LUMA, PMP_CHROMA = 0, 1
+NET_IDS = {"Luma_Q": 0, "Luma_MSBD": 1, "Chroma_Q": 2, "Chroma_MSBD": 3}
+ERRORS = {-1: "PMP_E_INVALID", -2: "PMP_E_HIP", -3: "PMP_E_NOWEIGHTS", -4: "PMP_E_IO", -5: "PMP_E_NOMEM", -6: "PMP_E_NODEVICE"}
+
+
+class PmpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (ERRORS.get(code, "PMP_E_?"), code, msg))
+        self.code = code
+
+
+class TensorDesc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("ndim", C.c_int), ("shape", C.c_int * 4), ("offset", C.c_int64)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/pmp.h
+_VP, _I, _I64, _U32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint32
+SIGNATURES = {
+    "pmp_version": (C.c_char_p, []),
+    "pmp_last_error": (C.c_char_p, [_VP]),
+    "pmp_create": (_I, [_I, C.POINTER(_VP)]),
+    "pmp_destroy": (_I, [_VP]),
+    "pmp_set_stream": (_I, [_VP, _VP]),
+    "pmp_synchronize": (_I, [_VP]),
+    "pmp_set_chunk": (_I, [_VP, _I]),
+    "pmp_load_weights": (_I, [_VP, _I, _I, _VP, C.POINTER(TensorDesc), _I]),
+    "pmp_has_weights": (_I, [_VP, _I, _I]),
+    "pmp_infer": (_I, [_VP, _I, _I, _VP, _VP, _VP, _I64, _VP, _VP, _VP]),
+    "pmp_infer_device": (_I, [_VP, _I, _I, _VP, _VP, _VP, _I64, _VP, _VP, _VP]),
+    "pmp_postprocess": (_I, [_VP, _I, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP]),
+    "pmp_postprocess_device": (_I, [_VP, _I, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP]),
+    "pmp_infer_postprocess": (_I, [_VP, _I, _I, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "pmp_infer_postprocess_device": (_I, [_VP, _I, _I, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "pmp_cut_blocks": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP]),
+    "pmp_cut_blocks_device": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP]),
+    "pmp_write_partition_file": (_I, [C.c_char_p, _I, _I, _I, _VP, _VP, _VP, _VP]),
+    "pmp_format_partition_text": (_I64, [_I, _I, _I, _VP, _VP, _VP, _VP, _VP, _I64]),
+    "pmp_ktime_enable": (_I, [_VP, _U32]),
+    "pmp_ktime_classes": (_I, []),
+    "pmp_ktime_name": (C.c_char_p, [_I]),
+    "pmp_ktime_get": (_I, [_VP, _I, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libpmp_hip.so.  Fails loudly when the extension has not been built: there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise ImportError("%s is missing - build it with `make -C %s` (or __graft_entry__.build())"
+                              % (LIB_PATH, os.path.join(_HERE, "csrc")))
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, ctx=None):
+    if rc < 0:
+        msg = load().pmp_last_error(ctx)
+        raise PmpError(int(rc), msg.decode() if msg else "")
+    return rc

@@ -1,0 +1,334 @@
+// conv_misc.hip — the non-MFMA kernels of the four nets: stems straight from the u8 blocks, the tiny tail convs,
+// the heads, and the gather-style glue (multi-scale pool concat, attention inputs).  Together < 3 % of the FLOPs.
+#include "pmp_kernels.h"
+
+namespace pmp {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ size_t act_idx(int n, int c, int y, int x, int CB, int H, int W)
+{
+    return ((((size_t)n * CB + (c >> 4)) * H + y) * W + x) * 16 + (c & 15);
+}
+
+// =============================================================================================== stems
+// One workgroup = one block.  The zero-padded input planes and all stem weights live in LDS; every thread owns one
+// output column and walks it in groups of 4 rows x 8 output channels (32 accumulators), sliding a register window
+// down the column so each LDS pixel read feeds up to KH taps.
+//
+//   luma   Q    : 1 plane 72x72,  conv 9x9 -> 32                      (Model_QBD.py:79-80)
+//   luma   MSBD : 2 planes 72x72, conv 9x9 -> 16, 5x9 -> 8, 9x5 -> 8  (Model_QBD.py:130-135)
+//   chroma Q    : 3 planes 36x36, conv 5x5 -> 32                      (Model_QBD.py:177-178)
+//   chroma MSBD : 4 planes 36x36, conv 5x5 -> 16, 3x5 -> 8, 5x3 -> 8  (Model_QBD.py:228-233)
+// Right/bottom zero padding of 4 (2) is common to all convs: the (5,9) conv pads right only but never reads below
+// row y+4 <= 67, the (9,5) conv pads bottom only but never reads right of x+4 <= 67.
+template <int KH, int KW, int CIN, int PS, int ROWS>
+__device__ __forceinline__ void stem_conv(const float *__restrict__ planes, const float *__restrict__ w,
+                                          const float *__restrict__ bias, int cout, int x, int y0, int OUT,
+                                          float *__restrict__ out_n, int ch_off)
+{
+    // planes: [CIN][PS][PS];  w: [KH*KW][CIN][cout];  computes rows y0..y0+ROWS-1 at column x for all cout.
+    for (int c0 = 0; c0 < cout; c0 += 8) {
+        float acc[ROWS][8];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[r][k] = bias[c0 + k];
+        for (int ci = 0; ci < CIN; ++ci) {
+            const float *pl = planes + ci * PS * PS;
+#pragma unroll
+            for (int dx = 0; dx < KW; ++dx) {
+                float col[ROWS + KH - 1];
+#pragma unroll
+                for (int r = 0; r < ROWS + KH - 1; ++r) col[r] = pl[(y0 + r) * PS + x + dx];
+#pragma unroll
+                for (int dy = 0; dy < KH; ++dy) {
+                    const float *wp = w + ((dy * KW + dx) * CIN + ci) * cout + c0;
+                    const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wp);
+                    const f32x4 w1 = *reinterpret_cast<const f32x4 *>(wp + 4);
+#pragma unroll
+                    for (int r = 0; r < ROWS; ++r) {
+                        const float v = col[r + dy];
+                        acc[r][0] = fmaf(v, w0.x, acc[r][0]); acc[r][1] = fmaf(v, w0.y, acc[r][1]);
+                        acc[r][2] = fmaf(v, w0.z, acc[r][2]); acc[r][3] = fmaf(v, w0.w, acc[r][3]);
+                        acc[r][4] = fmaf(v, w1.x, acc[r][4]); acc[r][5] = fmaf(v, w1.y, acc[r][5]);
+                        acc[r][6] = fmaf(v, w1.z, acc[r][6]); acc[r][7] = fmaf(v, w1.w, acc[r][7]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int c = ch_off + c0;  // 8 consecutive channels inside one 16-channel group
+            float *o = out_n + (((size_t)(c >> 4) * OUT + (y0 + r)) * OUT + x) * 16 + (c & 15);
+            f32x4 v0 = {fmaxf(acc[r][0], 0.f), fmaxf(acc[r][1], 0.f), fmaxf(acc[r][2], 0.f), fmaxf(acc[r][3], 0.f)};
+            f32x4 v1 = {fmaxf(acc[r][4], 0.f), fmaxf(acc[r][5], 0.f), fmaxf(acc[r][6], 0.f), fmaxf(acc[r][7], 0.f)};
+            *reinterpret_cast<f32x4 *>(o) = v0;
+            *reinterpret_cast<f32x4 *>(o + 4) = v1;
+        }
+    }
+}
+
+template <bool LUMA, bool MSBD>
+__global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
+{
+    constexpr int S = LUMA ? 68 : 34, P = LUMA ? 4 : 2, PS = S + P, OUT = S - P;  // 72/36 planes, 64/32 outputs
+    constexpr int CIN = (LUMA ? 1 : 3) + (MSBD ? 1 : 0);
+    constexpr int K1 = LUMA ? 9 : 5, K2 = LUMA ? 5 : 3;
+    constexpr int NW = MSBD ? (K1 * K1 * CIN * 16 + 2 * K2 * K1 * CIN * 8) : (K1 * K1 * CIN * 32);
+    extern __shared__ float smem[];
+    float *planes = smem;                 // [CIN][PS][PS]
+    float *wl = smem + CIN * PS * PS;     // NW floats, then 32 biases
+    float *bl = wl + NW;
+    const int n = blockIdx.x, tid = threadIdx.x;
+
+    for (int i = tid; i < NW; i += 256) wl[i] = a.w[i];
+    if (tid < 32) bl[tid] = a.bias[tid];
+    const uint8_t *by = a.by + (size_t)n * 68 * 68;
+    for (int i = tid; i < PS * PS; i += 256) {
+        const int r = i / PS, c = i - r * PS;
+        const bool in = r < S && c < S;
+        if (LUMA) {
+            planes[i] = in ? (float)by[r * 68 + c] : 0.f;
+        } else {
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+            if (in) {
+                const uint8_t *p = by + (2 * r) * 68 + 2 * c;  // F.max_pool2d(Y, 2), Inference_QBD.py:197
+                const int m = max(max((int)p[0], (int)p[1]), max((int)p[68], (int)p[69]));
+                v0 = (float)m;
+                v1 = (float)a.bu[(size_t)n * 34 * 34 + r * 34 + c];
+                v2 = (float)a.bv[(size_t)n * 34 * 34 + r * 34 + c];
+            }
+            planes[i] = v0; planes[PS * PS + i] = v1; planes[2 * PS * PS + i] = v2;
+        }
+        if (MSBD) {  // padding_lu(interpolate(q, 8 | 4)), Model_QBD.py:130 / :228
+            float qv = 0.f;
+            if (in && r >= P && c >= P) {
+                constexpr int SC = LUMA ? 8 : 4;
+                qv = a.q[(size_t)n * 64 + ((r - P) / SC) * 8 + (c - P) / SC];
+            }
+            planes[(CIN - 1) * PS * PS + i] = qv;
+        }
+    }
+    __syncthreads();
+
+    float *out_n = a.out + (size_t)n * 2 * OUT * OUT * 16;
+    constexpr int COLS_PER_WG = 256 / OUT;       // luma: 4 row-bands of 16 rows; chroma: 8 bands of 4 rows
+    constexpr int BAND = OUT / COLS_PER_WG;
+    const int x = tid % OUT, band = tid / OUT;
+    for (int y0 = band * BAND; y0 < (band + 1) * BAND; y0 += 4) {
+        if (MSBD) {
+            stem_conv<K1, K1, CIN, PS, 4>(planes, wl, bl, 16, x, y0, OUT, out_n, 0);
+            stem_conv<K2, K1, CIN, PS, 4>(planes, wl + K1 * K1 * CIN * 16, bl + 16, 8, x, y0, OUT, out_n, 16);
+            stem_conv<K1, K2, CIN, PS, 4>(planes, wl + K1 * K1 * CIN * 16 + K2 * K1 * CIN * 8, bl + 24, 8, x, y0, OUT,
+                                          out_n, 24);
+        } else {
+            stem_conv<K1, K1, CIN, PS, 4>(planes, wl, bl, 32, x, y0, OUT, out_n, 0);
+        }
+    }
+}
+
+template <bool LUMA, bool MSBD>
+static hipError_t launch_stem_t(hipStream_t s, const StemArgs &a)
+{
+    constexpr int S = LUMA ? 68 : 34, P = LUMA ? 4 : 2, PS = S + P;
+    constexpr int CIN = (LUMA ? 1 : 3) + (MSBD ? 1 : 0);
+    constexpr int K1 = LUMA ? 9 : 5, K2 = LUMA ? 5 : 3;
+    constexpr int NW = MSBD ? (K1 * K1 * CIN * 16 + 2 * K2 * K1 * CIN * 8) : (K1 * K1 * CIN * 32);
+    const size_t smem = (size_t)(CIN * PS * PS + NW + 32) * sizeof(float);
+    hipLaunchKernelGGL((stem_kernel<LUMA, MSBD>), dim3(a.N), dim3(256), smem, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_stem(hipStream_t s, bool luma, bool msbd, const StemArgs &a)
+{
+    if (luma) return msbd ? launch_stem_t<true, true>(s, a) : launch_stem_t<true, false>(s, a);
+    return msbd ? launch_stem_t<false, true>(s, a) : launch_stem_t<false, false>(s, a);
+}
+
+// =============================================================================================== small direct conv
+// One thread per (n, y, x, cout).  Only used where the whole layer is a few hundred MAC per output on 8x8 maps.
+__global__ __launch_bounds__(256) void conv_direct_kernel(ConvDirectArgs a)
+{
+    const size_t total = (size_t)a.N * a.H * a.W * a.CoutPad;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int co = (int)(i % a.CoutPad);
+    size_t r = i / a.CoutPad;
+    const int x = (int)(r % a.W); r /= a.W;
+    const int y = (int)(r % a.H);
+    const int n = (int)(r / a.H);
+    const int CBo = a.CoutPad >> 4;
+    float acc = 0.f;
+    if (co < a.Cout) {
+        if (a.bias) acc = a.bias[co];
+        const int py = a.KH / 2, px = a.KW / 2, CBi = a.CinPad >> 4;
+        for (int dy = 0; dy < a.KH; ++dy) {
+            const int yy = y + dy - py;
+            if (yy < 0 || yy >= a.H) continue;
+            for (int dx = 0; dx < a.KW; ++dx) {
+                const int xx = x + dx - px;
+                if (xx < 0 || xx >= a.W) continue;
+                const float *wp = a.w + (size_t)((dy * a.KW + dx) * a.Cin) * a.Cout + co;
+                for (int ci = 0; ci < a.Cin; ++ci)
+                    acc = fmaf(a.x[act_idx(n, ci, yy, xx, CBi, a.H, a.W)], wp[(size_t)ci * a.Cout], acc);
+            }
+        }
+        if (a.x_sc) {
+            const int CBs = a.CscPad >> 4;
+            for (int ci = 0; ci < a.Csc; ++ci)
+                acc = fmaf(a.x_sc[act_idx(n, ci, y, x, CBs, a.H, a.W)], a.w_sc[(size_t)ci * a.Cout + co], acc);
+        }
+        if (a.res) acc += a.res[act_idx(n, co, y, x, CBo, a.H, a.W)];
+        if (a.relu) acc = fmaxf(acc, 0.f);
+    }
+    a.out[act_idx(n, co, y, x, CBo, a.H, a.W)] = acc;  // padded channels are written as zeros
+}
+
+hipError_t launch_conv_direct(hipStream_t s, const ConvDirectArgs &a)
+{
+    const size_t total = (size_t)a.N * a.H * a.W * a.CoutPad;
+    hipLaunchKernelGGL(conv_direct_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// =============================================================================================== heads
+__global__ __launch_bounds__(256) void head_kernel(HeadArgs a)
+{
+    const int S = a.S, cout = a.layer < 0 ? 1 : 2;
+    const size_t total = (size_t)a.N * S * S;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % S), y = (int)((i / S) % S), n = (int)(i / ((size_t)S * S));
+    float acc0 = a.bias[0], acc1 = cout > 1 ? a.bias[1] : 0.f;
+    for (int dy = 0; dy < 3; ++dy) {
+        const int yy = y + dy - 1;
+        if (yy < 0 || yy >= S) continue;
+        for (int dx = 0; dx < 3; ++dx) {
+            const int xx = x + dx - 1;
+            if (xx < 0 || xx >= S) continue;
+            const float *xp = a.x + (((size_t)n * S + yy) * S + xx) * 16;
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(xp), v1 = *reinterpret_cast<const f32x4 *>(xp + 4);
+            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            const float *wp = a.w + (dy * 3 + dx) * 8 * cout;
+#pragma unroll
+            for (int ci = 0; ci < 8; ++ci) {
+                acc0 = fmaf(v[ci], wp[ci * cout], acc0);
+                if (cout > 1) acc1 = fmaf(v[ci], wp[ci * cout + 1], acc1);
+            }
+        }
+    }
+    if (a.layer < 0) {
+        a.qt[(size_t)n * 64 + y * 8 + x] = acc0;
+    } else {
+        const size_t o = ((size_t)n * 3 + a.layer) * 256 + y * 16 + x;
+        if (a.layer > 0) acc0 += a.bt[o - 256];  // out_k[:,0] += out_{k-1}[:,0]  (Model_QBD.py:146, :153)
+        a.bt[o] = acc0;
+        a.dire[o] = acc1;
+    }
+}
+
+hipError_t launch_head(hipStream_t s, const HeadArgs &a)
+{
+    const size_t total = (size_t)a.N * a.S * a.S;
+    hipLaunchKernelGGL(head_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// =============================================================================================== glue
+// cat[x5, up2(mp2(x5)), up4(mp4(x5)), up8(mp8(x5))]: one workgroup per (block, 16-channel group of x5).
+__global__ __launch_bounds__(256) void multipool_concat_kernel(const float *__restrict__ x5, float *__restrict__ x6)
+{
+    __shared__ float t[16 * 16 * 16];
+    __shared__ float p2[8 * 8 * 16], p4[4 * 4 * 16], p8[2 * 2 * 16];
+    const int n = blockIdx.x >> 1, cb = blockIdx.x & 1, tid = threadIdx.x;
+    const float *src = x5 + ((size_t)n * 2 + cb) * 4096;
+    for (int i = tid; i < 4096; i += 256) t[i] = src[i];
+    __syncthreads();
+    for (int i = tid; i < 8 * 8 * 16; i += 256) {
+        const int c = i & 15, x = (i >> 4) & 7, y = i >> 7;
+        const float *q = t + ((2 * y) * 16 + 2 * x) * 16 + c;
+        p2[i] = fmaxf(fmaxf(q[0], q[16]), fmaxf(q[256], q[272]));
+    }
+    __syncthreads();
+    if (tid < 4 * 4 * 16) {
+        const int c = tid & 15, x = (tid >> 4) & 3, y = tid >> 6;
+        const float *q = p2 + ((2 * y) * 8 + 2 * x) * 16 + c;
+        p4[tid] = fmaxf(fmaxf(q[0], q[16]), fmaxf(q[128], q[144]));
+    }
+    __syncthreads();
+    if (tid < 2 * 2 * 16) {
+        const int c = tid & 15, x = (tid >> 4) & 1, y = tid >> 5;
+        const float *q = p4 + ((2 * y) * 4 + 2 * x) * 16 + c;
+        p8[tid] = fmaxf(fmaxf(q[0], q[16]), fmaxf(q[64], q[80]));
+    }
+    __syncthreads();
+    float *dst = x6 + (size_t)n * 8 * 4096;  // channel groups: x5 -> 0,1; mp2 -> 2,3; mp4 -> 4,5; mp8 -> 6,7
+    for (int i = tid; i < 4096; i += 256) {
+        const int c = i & 15, x = (i >> 4) & 15, y = i >> 8;
+        dst[(size_t)(0 + cb) * 4096 + i] = t[i];
+        dst[(size_t)(2 + cb) * 4096 + i] = p2[((y >> 1) * 8 + (x >> 1)) * 16 + c];
+        dst[(size_t)(4 + cb) * 4096 + i] = p4[((y >> 2) * 4 + (x >> 2)) * 16 + c];
+        dst[(size_t)(6 + cb) * 4096 + i] = p8[((y >> 3) * 2 + (x >> 3)) * 16 + c];
+    }
+}
+
+hipError_t launch_multipool_concat(hipStream_t s, const float *x5, float *x6, int N)
+{
+    hipLaunchKernelGGL(multipool_concat_kernel, dim3(N * 2), dim3(256), 0, s, x5, x6);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void att_input_kernel(const float *__restrict__ q, const float *__restrict__ bt,
+                                                        const float *__restrict__ dire, int layer,
+                                                        float *__restrict__ out, int N, int S)
+{
+    const size_t total = (size_t)N * S * S;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % S), y = (int)((i / S) % S), n = (int)(i / ((size_t)S * S));
+    const int sq = S / 8, sh = S / 16;
+    const size_t o = ((size_t)n * 3 + layer) * 256 + (y / sh) * 16 + (x / sh);
+    f32x4 v = {q[(size_t)n * 64 + (y / sq) * 8 + (x / sq)], bt[o], dire[o], 0.f};
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 *dst = reinterpret_cast<f32x4 *>(out + i * 16);
+    dst[0] = v; dst[1] = z; dst[2] = z; dst[3] = z;
+}
+
+hipError_t launch_att_input(hipStream_t s, const float *q, const float *bt, const float *dire, int layer, float *out,
+                            int N, int S)
+{
+    const size_t total = (size_t)N * S * S;
+    hipLaunchKernelGGL(att_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, q, bt, dire, layer, out,
+                       N, S);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void maxpool2_kernel(const float *__restrict__ x, float *__restrict__ out, size_t total,
+                                                       int H, int W)
+{
+    // one thread per output float4: index = ((plane*Ho + yo)*Wo + xo)*4 + s
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int s = (int)(i & 3);
+    size_t r = i >> 2;
+    const int xo = (int)(r % Wo); r /= Wo;
+    const int yo = (int)(r % Ho);
+    const size_t plane = r / Ho;
+    const f32x4 *p = reinterpret_cast<const f32x4 *>(x) + ((plane * H + 2 * yo) * W + 2 * xo) * 4 + s;
+    const f32x4 a = p[0], b = p[4], c = p[(size_t)W * 4], d = p[(size_t)W * 4 + 4];
+    f32x4 v;
+    v.x = fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, d.x)); v.y = fmaxf(fmaxf(a.y, b.y), fmaxf(c.y, d.y));
+    v.z = fmaxf(fmaxf(a.z, b.z), fmaxf(c.z, d.z)); v.w = fmaxf(fmaxf(a.w, b.w), fmaxf(c.w, d.w));
+    reinterpret_cast<f32x4 *>(out)[i] = v;
+}
+
+hipError_t launch_maxpool2(hipStream_t s, const float *x, float *out, int N, int C, int H, int W)
+{
+    const size_t total = (size_t)N * (C >> 4) * (H >> 1) * (W >> 1) * 4;
+    hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, out, total, H, W);
+    return hipGetLastError();
+}
+
+}  // namespace pmp

@@ -1,0 +1,469 @@
+// pmp_api.cpp — the C ABI declared in include/pmp.h.
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "pmp_host.h"
+
+namespace pmp {
+
+static thread_local std::string g_err;
+
+int set_err(pmp_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg;
+    g_err = msg;
+    return code;
+}
+
+int hip_fail(pmp_ctx *c, hipError_t e, const char *what)
+{
+    return set_err(c, PMP_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+static int ensure(pmp_ctx *c, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return PMP_OK;
+    if (b.p) { hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) { b.p = nullptr; return set_err(c, PMP_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    b.cap = bytes;
+    return PMP_OK;
+}
+
+// ---- kernel-class timing ---------------------------------------------------------------------------------
+static hipEvent_t get_event(pmp_ctx *c)
+{
+    if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+
+KScope::KScope(pmp_ctx *c_, int cls_, double flops_) : c(c_), cls(cls_), on(false), a(nullptr), b(nullptr), flops(flops_)
+{
+    on = (c->kmask >> cls) & 1u;
+    if (on) { a = get_event(c); b = get_event(c); hipEventRecord(a, c->stream); }
+}
+
+KScope::~KScope()
+{
+    if (on) { hipEventRecord(b, c->stream); c->krec[cls].push_back(KTimeRec{a, b, flops}); }
+}
+
+static void ktime_drain(pmp_ctx *c)
+{
+    for (int k = 0; k < K_NCLASS; ++k) {
+        for (auto &r : c->krec[k]) {
+            float ms = 0.f;
+            hipEventSynchronize(r.b);
+            if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { c->kms[k] += ms; c->klaunch[k] += 1; c->kflops[k] += r.flops; }
+            c->event_pool.push_back(r.a);
+            c->event_pool.push_back(r.b);
+        }
+        c->krec[k].clear();
+    }
+}
+
+static const NetWeights *find_net(pmp_ctx *c, int net_id, int qp)
+{
+    auto it = c->nets.find(net_id * 100 + qp);
+    return (it == c->nets.end() || !it->second.loaded) ? nullptr : &it->second;
+}
+
+// Runs forward (measure pass, then real) for n <= chunk blocks.
+template <typename F>
+static int run_graph(pmp_ctx *c, F &&fwd)
+{
+    c->arena.measuring = true;
+    c->arena.off = 0;
+    int rc = fwd();
+    if (rc != PMP_OK) return rc;
+    if ((rc = ensure(c, c->ws, c->arena.off)) != PMP_OK) return rc;
+    c->arena.base = static_cast<char *>(c->ws.p);
+    c->arena.cap = c->ws.cap;
+    c->arena.measuring = false;
+    c->arena.off = 0;
+    return fwd();
+}
+
+static int infer_device_impl(pmp_ctx *c, int comp, int qp, const uint8_t *by, const uint8_t *bu, const uint8_t *bv,
+                             int64_t n, float *qt, float *bt, float *dire)
+{
+    if (comp != PMP_LUMA && comp != PMP_CHROMA) return set_err(c, PMP_E_INVALID, "pmp_infer: comp must be PMP_LUMA or PMP_CHROMA");
+    if (n < 0 || !by || !qt || !bt || !dire || (comp == PMP_CHROMA && (!bu || !bv)))
+        return set_err(c, PMP_E_INVALID, "pmp_infer: null buffer or negative count");
+    const bool luma = comp == PMP_LUMA;
+    const NetWeights *wq = find_net(c, luma ? PMP_NET_LUMA_Q : PMP_NET_CHROMA_Q, qp);
+    const NetWeights *wb = find_net(c, luma ? PMP_NET_LUMA_MSBD : PMP_NET_CHROMA_MSBD, qp);
+    if (!wq || !wb) return set_err(c, PMP_E_NOWEIGHTS, "pmp_infer: weights for this (comp, qp) are not loaded");
+    for (int64_t o = 0; o < n; o += c->chunk) {
+        const int m = (int)((n - o) < c->chunk ? (n - o) : c->chunk);
+        const uint8_t *y = by + o * 68 * 68;
+        const uint8_t *u = bu ? bu + o * 34 * 34 : nullptr, *v = bv ? bv + o * 34 * 34 : nullptr;
+        float *q = qt + o * 64;
+        int rc = run_graph(c, [&] { return forward_q(c, luma, *wq, y, u, v, m, q); });
+        if (rc != PMP_OK) return rc;
+        rc = run_graph(c, [&] { return forward_msbd(c, luma, *wb, y, u, v, q, m, bt + o * 768, dire + o * 768); });
+        if (rc != PMP_OK) return rc;
+    }
+    return PMP_OK;
+}
+
+static int post_device_impl(pmp_ctx *c, int comp, const float *qt, const float *bt, const float *dire, int64_t n,
+                            uint8_t *hor, uint8_t *ver, uint8_t *qt_u8, int8_t *dire_i8)
+{
+    if (comp != PMP_LUMA && comp != PMP_CHROMA) return set_err(c, PMP_E_INVALID, "pmp_postprocess: bad comp");
+    if (n < 0 || !qt || !bt || !dire || !hor || !ver || !qt_u8 || !dire_i8)
+        return set_err(c, PMP_E_INVALID, "pmp_postprocess: null buffer or negative count");
+    KScope ks(c, K_POST, 0.0);
+    hipError_t e = launch_postprocess(c->stream, qt, bt, dire, n, comp == PMP_LUMA ? 1 : 2, hor, ver, qt_u8, dire_i8);
+    return e == hipSuccess ? PMP_OK : hip_fail(c, e, "postprocess");
+}
+
+static int sync(pmp_ctx *c)
+{
+    hipError_t e = hipStreamSynchronize(c->stream);
+    return e == hipSuccess ? PMP_OK : hip_fail(c, e, "hipStreamSynchronize");
+}
+
+static int h2d(pmp_ctx *c, DevBuf &b, const void *src, size_t bytes)
+{
+    int rc = ensure(c, b, bytes ? bytes : 1);
+    if (rc != PMP_OK) return rc;
+    if (!bytes) return PMP_OK;
+    hipError_t e = hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream);
+    return e == hipSuccess ? PMP_OK : hip_fail(c, e, "hipMemcpyAsync(H2D)");
+}
+
+static int d2h(pmp_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!bytes || !dst) return PMP_OK;
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream);
+    return e == hipSuccess ? PMP_OK : hip_fail(c, e, "hipMemcpyAsync(D2H)");
+}
+
+}  // namespace pmp
+
+using namespace pmp;
+
+#define CHECK_CTX(c) do { if (!(c)) return set_err(nullptr, PMP_E_INVALID, "null context"); hipSetDevice((c)->device); } while (0)
+
+extern "C" {
+
+const char *pmp_version(void) { return "pmp-hip 0.1 (gfx950, fp32 MFMA)"; }
+
+const char *pmp_last_error(const pmp_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int pmp_create(int device_id, pmp_ctx **out)
+{
+    if (!out) return set_err(nullptr, PMP_E_INVALID, "pmp_create: out is null");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return set_err(nullptr, PMP_E_NODEVICE, "pmp_create: no HIP device (this library has no CPU fallback)");
+    if (device_id < 0 || device_id >= ndev) return set_err(nullptr, PMP_E_INVALID, "pmp_create: device_id out of range");
+    if ((e = hipSetDevice(device_id)) != hipSuccess) return hip_fail(nullptr, e, "hipSetDevice");
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return hip_fail(nullptr, e, "hipGetDeviceProperties");
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return set_err(nullptr, PMP_E_NODEVICE, std::string("pmp_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+    pmp_ctx *c = new (std::nothrow) pmp_ctx();
+    if (!c) return set_err(nullptr, PMP_E_NOMEM, "pmp_create: out of host memory");
+    c->device = device_id;
+    if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return hip_fail(nullptr, e, "hipStreamCreate"); }
+    c->stream = c->own_stream;
+    *out = c;
+    return PMP_OK;
+}
+
+int pmp_destroy(pmp_ctx *c)
+{
+    if (!c) return PMP_OK;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    ktime_drain(c);
+    for (auto &kv : c->nets) free_net_weights(kv.second);
+    for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
+    DevBuf *bufs[] = {&c->ws, &c->d_in[0], &c->d_in[1], &c->d_in[2], &c->d_logit[0], &c->d_logit[1], &c->d_logit[2],
+                      &c->d_out[0], &c->d_out[1], &c->d_out[2], &c->d_out[3], &c->d_frames[0], &c->d_frames[1], &c->d_frames[2]};
+    for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
+    hipStreamDestroy(c->own_stream);
+    delete c;
+    return PMP_OK;
+}
+
+int pmp_set_stream(pmp_ctx *c, void *hip_stream)
+{
+    CHECK_CTX(c);
+    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return PMP_OK;
+}
+
+int pmp_synchronize(pmp_ctx *c) { CHECK_CTX(c); return sync(c); }
+
+int pmp_set_chunk(pmp_ctx *c, int blocks)
+{
+    CHECK_CTX(c);
+    if (blocks < 1 || blocks > 65536) return set_err(c, PMP_E_INVALID, "pmp_set_chunk: 1..65536");
+    c->chunk = blocks;
+    return PMP_OK;
+}
+
+int pmp_load_weights(pmp_ctx *c, int net_id, int qp, const float *blob, const pmp_tensor_desc *descs, int ndesc)
+{
+    CHECK_CTX(c);
+    int rc = sync(c);
+    if (rc != PMP_OK) return rc;
+    return load_net_weights(c, net_id, qp, blob, descs, ndesc);
+}
+
+int pmp_has_weights(const pmp_ctx *c, int net_id, int qp)
+{
+    if (!c) return 0;
+    auto it = c->nets.find(net_id * 100 + qp);
+    return it != c->nets.end() && it->second.loaded;
+}
+
+int pmp_infer_device(pmp_ctx *c, int comp, int qp, const uint8_t *by, const uint8_t *bu, const uint8_t *bv, int64_t n,
+                     float *qt, float *bt, float *dire)
+{
+    CHECK_CTX(c);
+    return infer_device_impl(c, comp, qp, by, bu, bv, n, qt, bt, dire);
+}
+
+int pmp_postprocess_device(pmp_ctx *c, int comp, const float *qt, const float *bt, const float *dire, int64_t n,
+                           uint8_t *hor, uint8_t *ver, uint8_t *qt_u8, int8_t *dire_i8)
+{
+    CHECK_CTX(c);
+    return post_device_impl(c, comp, qt, bt, dire, n, hor, ver, qt_u8, dire_i8);
+}
+
+int pmp_infer_postprocess_device(pmp_ctx *c, int comp, int qp, const uint8_t *by, const uint8_t *bu, const uint8_t *bv,
+                                 int64_t n, uint8_t *hor, uint8_t *ver, uint8_t *qt_u8, int8_t *dire_i8, float *qt,
+                                 float *bt, float *dire)
+{
+    CHECK_CTX(c);
+    int rc;
+    if (!qt) { if ((rc = ensure(c, c->d_logit[0], (size_t)(n ? n : 1) * 64 * 4))) return rc; qt = (float *)c->d_logit[0].p; }
+    if (!bt) { if ((rc = ensure(c, c->d_logit[1], (size_t)(n ? n : 1) * 768 * 4))) return rc; bt = (float *)c->d_logit[1].p; }
+    if (!dire) { if ((rc = ensure(c, c->d_logit[2], (size_t)(n ? n : 1) * 768 * 4))) return rc; dire = (float *)c->d_logit[2].p; }
+    if ((rc = infer_device_impl(c, comp, qp, by, bu, bv, n, qt, bt, dire))) return rc;
+    return post_device_impl(c, comp, qt, bt, dire, n, hor, ver, qt_u8, dire_i8);
+}
+
+// ---- host-pointer entry points: stage through device buffers owned by the context ------------------------
+static int stage_blocks(pmp_ctx *c, int comp, const uint8_t *by, const uint8_t *bu, const uint8_t *bv, int64_t n)
+{
+    int rc;
+    if ((rc = h2d(c, c->d_in[0], by, (size_t)n * 68 * 68))) return rc;
+    if (comp == PMP_CHROMA) {
+        if ((rc = h2d(c, c->d_in[1], bu, (size_t)n * 34 * 34))) return rc;
+        if ((rc = h2d(c, c->d_in[2], bv, (size_t)n * 34 * 34))) return rc;
+    }
+    return PMP_OK;
+}
+
+int pmp_infer(pmp_ctx *c, int comp, int qp, const uint8_t *by, const uint8_t *bu, const uint8_t *bv, int64_t n, float *qt,
+              float *bt, float *dire)
+{
+    CHECK_CTX(c);
+    if (n < 0 || !by || !qt || !bt || !dire || (comp == PMP_CHROMA && (!bu || !bv)))
+        return set_err(c, PMP_E_INVALID, "pmp_infer: null buffer or negative count");
+    if (n == 0) return PMP_OK;
+    int rc;
+    if ((rc = stage_blocks(c, comp, by, bu, bv, n))) return rc;
+    if ((rc = ensure(c, c->d_logit[0], (size_t)n * 64 * 4)) || (rc = ensure(c, c->d_logit[1], (size_t)n * 768 * 4)) ||
+        (rc = ensure(c, c->d_logit[2], (size_t)n * 768 * 4)))
+        return rc;
+    float *dq = (float *)c->d_logit[0].p, *db = (float *)c->d_logit[1].p, *dd = (float *)c->d_logit[2].p;
+    if ((rc = infer_device_impl(c, comp, qp, (const uint8_t *)c->d_in[0].p, (const uint8_t *)c->d_in[1].p,
+                                (const uint8_t *)c->d_in[2].p, n, dq, db, dd)))
+        return rc;
+    if ((rc = d2h(c, qt, dq, (size_t)n * 64 * 4)) || (rc = d2h(c, bt, db, (size_t)n * 768 * 4)) ||
+        (rc = d2h(c, dire, dd, (size_t)n * 768 * 4)))
+        return rc;
+    return sync(c);
+}
+
+static int alloc_out(pmp_ctx *c, int64_t n)
+{
+    int rc;
+    if ((rc = ensure(c, c->d_out[0], (size_t)n * 256)) || (rc = ensure(c, c->d_out[1], (size_t)n * 256)) ||
+        (rc = ensure(c, c->d_out[2], (size_t)n * 64)) || (rc = ensure(c, c->d_out[3], (size_t)n * 768)))
+        return rc;
+    return PMP_OK;
+}
+
+static int fetch_out(pmp_ctx *c, int64_t n, uint8_t *hor, uint8_t *ver, uint8_t *qt_u8, int8_t *dire_i8)
+{
+    int rc;
+    if ((rc = d2h(c, hor, c->d_out[0].p, (size_t)n * 256)) || (rc = d2h(c, ver, c->d_out[1].p, (size_t)n * 256)) ||
+        (rc = d2h(c, qt_u8, c->d_out[2].p, (size_t)n * 64)) || (rc = d2h(c, dire_i8, c->d_out[3].p, (size_t)n * 768)))
+        return rc;
+    return sync(c);
+}
+
+int pmp_postprocess(pmp_ctx *c, int comp, const float *qt, const float *bt, const float *dire, int64_t n, uint8_t *hor,
+                    uint8_t *ver, uint8_t *qt_u8, int8_t *dire_i8)
+{
+    CHECK_CTX(c);
+    if (n < 0 || !qt || !bt || !dire || !hor || !ver || !qt_u8 || !dire_i8)
+        return set_err(c, PMP_E_INVALID, "pmp_postprocess: null buffer or negative count");
+    if (n == 0) return PMP_OK;
+    int rc;
+    if ((rc = h2d(c, c->d_logit[0], qt, (size_t)n * 64 * 4)) || (rc = h2d(c, c->d_logit[1], bt, (size_t)n * 768 * 4)) ||
+        (rc = h2d(c, c->d_logit[2], dire, (size_t)n * 768 * 4)) || (rc = alloc_out(c, n)))
+        return rc;
+    if ((rc = post_device_impl(c, comp, (float *)c->d_logit[0].p, (float *)c->d_logit[1].p, (float *)c->d_logit[2].p, n,
+                               (uint8_t *)c->d_out[0].p, (uint8_t *)c->d_out[1].p, (uint8_t *)c->d_out[2].p,
+                               (int8_t *)c->d_out[3].p)))
+        return rc;
+    return fetch_out(c, n, hor, ver, qt_u8, dire_i8);
+}
+
+int pmp_infer_postprocess(pmp_ctx *c, int comp, int qp, const uint8_t *by, const uint8_t *bu, const uint8_t *bv, int64_t n,
+                          uint8_t *hor, uint8_t *ver, uint8_t *qt_u8, int8_t *dire_i8, float *qt, float *bt, float *dire)
+{
+    CHECK_CTX(c);
+    if (n < 0 || !by || !hor || !ver || !qt_u8 || !dire_i8 || (comp == PMP_CHROMA && (!bu || !bv)))
+        return set_err(c, PMP_E_INVALID, "pmp_infer_postprocess: null buffer or negative count");
+    if (n == 0) return PMP_OK;
+    int rc;
+    if ((rc = stage_blocks(c, comp, by, bu, bv, n)) || (rc = alloc_out(c, n))) return rc;
+    if ((rc = ensure(c, c->d_logit[0], (size_t)n * 64 * 4)) || (rc = ensure(c, c->d_logit[1], (size_t)n * 768 * 4)) ||
+        (rc = ensure(c, c->d_logit[2], (size_t)n * 768 * 4)))
+        return rc;
+    float *dq = (float *)c->d_logit[0].p, *db = (float *)c->d_logit[1].p, *dd = (float *)c->d_logit[2].p;
+    if ((rc = infer_device_impl(c, comp, qp, (const uint8_t *)c->d_in[0].p, (const uint8_t *)c->d_in[1].p,
+                                (const uint8_t *)c->d_in[2].p, n, dq, db, dd)))
+        return rc;
+    if ((rc = post_device_impl(c, comp, dq, db, dd, n, (uint8_t *)c->d_out[0].p, (uint8_t *)c->d_out[1].p,
+                               (uint8_t *)c->d_out[2].p, (int8_t *)c->d_out[3].p)))
+        return rc;
+    if ((rc = d2h(c, qt, dq, (size_t)n * 64 * 4)) || (rc = d2h(c, bt, db, (size_t)n * 768 * 4)) ||
+        (rc = d2h(c, dire, dd, (size_t)n * 768 * 4)))
+        return rc;
+    return fetch_out(c, n, hor, ver, qt_u8, dire_i8);
+}
+
+int pmp_cut_blocks_device(pmp_ctx *c, const void *y, const void *u, const void *v, int F, int H, int W, int bitdepth,
+                          uint8_t *by, uint8_t *bu, uint8_t *bv)
+{
+    CHECK_CTX(c);
+    if (!y || !u || !v || !by || !bu || !bv || F < 0 || H < 0 || W < 0 || (H & 1) || (W & 1) || (bitdepth != 8 && bitdepth != 10))
+        return set_err(c, PMP_E_INVALID, "pmp_cut_blocks: bad arguments (bitdepth 8 or 10, even H/W)");
+    hipError_t e = launch_cut_blocks(c->stream, y, u, v, F, H, W, bitdepth, by, bu, bv);
+    return e == hipSuccess ? PMP_OK : hip_fail(c, e, "cut_blocks");
+}
+
+int pmp_cut_blocks(pmp_ctx *c, const void *y, const void *u, const void *v, int F, int H, int W, int bitdepth, uint8_t *by,
+                   uint8_t *bu, uint8_t *bv)
+{
+    CHECK_CTX(c);
+    if (!y || !u || !v || !by || !bu || !bv || F < 0 || H < 0 || W < 0 || (H & 1) || (W & 1) || (bitdepth != 8 && bitdepth != 10))
+        return set_err(c, PMP_E_INVALID, "pmp_cut_blocks: bad arguments (bitdepth 8 or 10, even H/W)");
+    const size_t bps = bitdepth == 8 ? 1 : 2, ny = (size_t)F * H * W * bps, nc = (size_t)F * (H / 2) * (W / 2) * bps;
+    const int64_t n = (int64_t)F * (H / 64) * (W / 64);
+    if (n == 0) return PMP_OK;
+    int rc;
+    if ((rc = h2d(c, c->d_frames[0], y, ny)) || (rc = h2d(c, c->d_frames[1], u, nc)) || (rc = h2d(c, c->d_frames[2], v, nc)))
+        return rc;
+    if ((rc = ensure(c, c->d_in[0], (size_t)n * 68 * 68)) || (rc = ensure(c, c->d_in[1], (size_t)n * 34 * 34)) ||
+        (rc = ensure(c, c->d_in[2], (size_t)n * 34 * 34)))
+        return rc;
+    hipError_t e = launch_cut_blocks(c->stream, c->d_frames[0].p, c->d_frames[1].p, c->d_frames[2].p, F, H, W, bitdepth,
+                                     (uint8_t *)c->d_in[0].p, (uint8_t *)c->d_in[1].p, (uint8_t *)c->d_in[2].p);
+    if (e != hipSuccess) return hip_fail(c, e, "cut_blocks");
+    if ((rc = d2h(c, by, c->d_in[0].p, (size_t)n * 68 * 68)) || (rc = d2h(c, bu, c->d_in[1].p, (size_t)n * 34 * 34)) ||
+        (rc = d2h(c, bv, c->d_in[2].p, (size_t)n * 34 * 34)))
+        return rc;
+    return sync(c);
+}
+
+// ---- PartitionMat text (Map2Partition.py:385-412) ---------------------------------------------------------
+int64_t pmp_format_partition_text(int frames, int H, int W, const uint8_t *hor, const uint8_t *ver, const uint8_t *qt_u8,
+                                  const int8_t *dire, char *buf, int64_t cap)
+{
+    if (frames < 0 || H < 0 || W < 0 || !hor || !ver || !qt_u8 || !dire) return set_err(nullptr, PMP_E_INVALID, "pmp_format_partition_text: bad arguments");
+    const int bh = H / 64, bw = W / 64, R = 16 * bh, C = 16 * bw;
+    int64_t pos = 0;
+    auto put = [&](int v) {  // values are in {-1, 0..3}: "d\n" or "-d\n"
+        if (v < 0) { if (buf && pos < cap) buf[pos] = '-'; ++pos; v = -v; }
+        if (v >= 100) { if (buf && pos < cap) buf[pos] = (char)('0' + v / 100); ++pos; }
+        if (v >= 10) { if (buf && pos < cap) buf[pos] = (char)('0' + (v / 10) % 10); ++pos; }
+        if (buf && pos < cap) buf[pos] = (char)('0' + v % 10);
+        ++pos;
+        if (buf && pos < cap) buf[pos] = '\n';
+        ++pos;
+    };
+    for (int f = 0; f < frames; ++f) {
+        const int64_t base = (int64_t)f * bh * bw;
+        for (int plane = 0; plane < 2; ++plane) {
+            const uint8_t *src = plane ? ver : hor;
+            for (int r = 0; r < R; ++r)
+                for (int cc = 0; cc < C; ++cc) put(src[(base + (r >> 4) * bw + (cc >> 4)) * 256 + (r & 15) * 16 + (cc & 15)]);
+        }
+        for (int r = 0; r < R / 2; ++r)
+            for (int cc = 0; cc < C / 2; ++cc) put(qt_u8[(base + (r >> 3) * bw + (cc >> 3)) * 64 + (r & 7) * 8 + (cc & 7)]);
+        for (int k = 0; k < 3; ++k)
+            for (int r = 0; r < R; ++r)
+                for (int cc = 0; cc < C; ++cc)
+                    put(dire[(base + (r >> 4) * bw + (cc >> 4)) * 768 + k * 256 + (r & 15) * 16 + (cc & 15)]);
+    }
+    if (buf && pos > cap) return set_err(nullptr, PMP_E_INVALID, "pmp_format_partition_text: buffer too small");
+    return pos;
+}
+
+int pmp_write_partition_file(const char *path, int frames, int H, int W, const uint8_t *hor, const uint8_t *ver,
+                             const uint8_t *qt_u8, const int8_t *dire)
+{
+    if (!path) return set_err(nullptr, PMP_E_INVALID, "pmp_write_partition_file: null path");
+    const int64_t need = pmp_format_partition_text(frames, H, W, hor, ver, qt_u8, dire, nullptr, 0);
+    if (need < 0) return (int)need;
+    std::string buf((size_t)need, '\0');
+    if (need && pmp_format_partition_text(frames, H, W, hor, ver, qt_u8, dire, &buf[0], need) != need)
+        return set_err(nullptr, PMP_E_INVALID, "pmp_write_partition_file: formatting failed");
+    FILE *fp = fopen(path, "wb");
+    if (!fp) return set_err(nullptr, PMP_E_IO, std::string("cannot open ") + path);
+    const size_t wr = need ? fwrite(buf.data(), 1, (size_t)need, fp) : 0;
+    const int cl = fclose(fp);
+    if (wr != (size_t)need || cl != 0) return set_err(nullptr, PMP_E_IO, std::string("short write to ") + path);
+    return PMP_OK;
+}
+
+// ---- timing ------------------------------------------------------------------------------------------------
+int pmp_ktime_classes(void) { return K_NCLASS; }
+
+const char *pmp_ktime_name(int cls)
+{
+    static const char *names[K_NCLASS] = {"conv_mfma_3x3_c64", "conv_mfma_5x5_c64", "conv_mfma_other", "stem", "small", "postprocess"};
+    return (cls >= 0 && cls < K_NCLASS) ? names[cls] : "";
+}
+
+int pmp_ktime_enable(pmp_ctx *c, uint32_t mask)
+{
+    CHECK_CTX(c);
+    int rc = sync(c);
+    if (rc != PMP_OK) return rc;
+    ktime_drain(c);
+    for (int k = 0; k < K_NCLASS; ++k) { c->klaunch[k] = 0; c->kms[k] = 0; c->kflops[k] = 0; }
+    c->kmask = mask;
+    return PMP_OK;
+}
+
+int pmp_ktime_get(pmp_ctx *c, int cls, int64_t *launches, double *ms, double *flops)
+{
+    CHECK_CTX(c);
+    if (cls < 0 || cls >= K_NCLASS) return set_err(c, PMP_E_INVALID, "pmp_ktime_get: bad class");
+    int rc = sync(c);
+    if (rc != PMP_OK) return rc;
+    ktime_drain(c);
+    if (launches) *launches = c->klaunch[cls];
+    if (ms) *ms = c->kms[cls];
+    if (flops) *flops = c->kflops[cls];
+    return PMP_OK;
+}
+
+}  // extern "C"

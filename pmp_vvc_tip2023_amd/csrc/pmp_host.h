@@ -1,0 +1,96 @@
+// Host-side internals of libpmp_hip.so: context, packed weights, the four forward graphs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/pmp.h"
+#include "pmp_kernels.h"
+
+namespace pmp {
+
+enum KClass { K_CONV3_64 = 0, K_CONV5_64, K_CONV_OTHER, K_STEM, K_SMALL, K_POST, K_NCLASS };
+
+struct DevBuf {  // grow-only device buffer
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+// ResidualBlock weights (Model_QBD.py:23-44), packed for the kernel that runs the block.
+struct RBWeights {
+    int cin = 0, cout = 0, k = 0;      // real dims
+    int cin_pad = 0, cout_pad = 0;
+    float *w0 = nullptr, *w2 = nullptr, *wsc = nullptr;  // MFMA packing (or direct packing when `direct`)
+    bool direct = false;               // 8x8 layers run on the direct kernel
+};
+
+struct NetWeights {
+    bool loaded = false;
+    std::map<std::string, RBWeights> rb;
+    float *stem_w = nullptr, *stem_b = nullptr;        // packed stem convs + 32 biases
+    float *head_w[3] = {nullptr, nullptr, nullptr};    // [9][8][cout]
+    float *head_b[3] = {nullptr, nullptr, nullptr};
+    std::vector<void *> allocs;
+};
+
+struct Arena {
+    char *base = nullptr;
+    size_t cap = 0, off = 0;
+    bool measuring = false;
+    float *get(size_t nfloats)
+    {
+        size_t bytes = (nfloats * sizeof(float) + 255) & ~(size_t)255;
+        float *p = measuring ? nullptr : reinterpret_cast<float *>(base + off);
+        off += bytes;
+        return p;
+    }
+};
+
+struct KTimeRec { hipEvent_t a, b; double flops; };
+
+}  // namespace pmp
+
+struct pmp_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    int chunk = 512;
+    std::string err;
+    std::map<int, pmp::NetWeights> nets;  // key = net_id * 100 + qp
+    pmp::Arena arena;
+    pmp::DevBuf ws;                        // activation workspace
+    pmp::DevBuf d_in[3], d_logit[3], d_out[4], d_frames[3];  // staging for the host-pointer entry points
+    // kernel-class timing
+    uint32_t kmask = 0;
+    std::vector<pmp::KTimeRec> krec[pmp::K_NCLASS];
+    std::vector<hipEvent_t> event_pool;
+    int64_t klaunch[pmp::K_NCLASS] = {0};
+    double kms[pmp::K_NCLASS] = {0}, kflops[pmp::K_NCLASS] = {0};
+};
+
+namespace pmp {
+
+int set_err(pmp_ctx *c, int code, const std::string &msg);
+int hip_fail(pmp_ctx *c, hipError_t e, const char *what);
+
+// weights_pack.cpp
+int load_net_weights(pmp_ctx *c, int net_id, int qp, const float *blob, const pmp_tensor_desc *descs, int ndesc);
+void free_net_weights(NetWeights &w);
+
+// nets.cpp: forward graphs on device pointers (n <= chunk); all launches go to c->stream.
+int forward_q(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, const uint8_t *bu, const uint8_t *bv,
+              int n, float *qt);
+int forward_msbd(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, const uint8_t *bu, const uint8_t *bv,
+                 const float *qt, int n, float *bt, float *dire);
+size_t workspace_floats_per_block(bool luma);
+
+// timing hooks used by nets.cpp
+struct KScope {
+    pmp_ctx *c; int cls; bool on; hipEvent_t a, b; double flops;
+    KScope(pmp_ctx *c, int cls, double flops);
+    ~KScope();
+};
+
+}  // namespace pmp

@@ -1,0 +1,87 @@
+// Internal launch interface between the host-side graph (nets.cpp / pmp_api.cpp) and the HIP kernels.
+//
+// Activation layout in HBM ("blocked channels-last"):  act[n][c/16][y][x][c%16]  float32, channels padded to a
+// multiple of 16 with zeros.  A 16-channel group of one tile row is contiguous (16 px * 64 B = 1 KiB), which is
+// exactly what one wave loads or stores per instruction in the MFMA conv kernel (16 B per lane, 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pmp {
+
+// ------------------------------------------------------------------------------------------------ conv (MFMA)
+// out = epilogue( conv_KHxKW(x, w) [+ conv_1x1(x_sc, w_sc)] [+ res] ), stride 1, zero padding K/2.
+// epilogue: optional ReLU, optional multiply by `gate`, optional 2x2 max-pool.  H, W multiples of 16;
+// Cin, Csc, Cout multiples of 16 (Cout <= 64).  Weight packing: pack_conv_mfma() in weights_pack.cpp.
+struct ConvMfmaArgs {
+    const float *x;     // [N][Cin/16][H][W][16]
+    const float *w;     // packed [Cin/16][KH*KW][Cout/16][64 lanes][4]
+    const float *x_sc;  // optional second source for the 1x1 shortcut conv, [N][Csc/16][H][W][16]
+    const float *w_sc;  // packed [Csc/16][1][Cout/16][64][4]
+    const float *res;   // optional identity residual [N][Cout/16][H][W][16]
+    const float *gate;  // optional gate (attention multiply), same shape as the un-pooled output
+    float *out;         // [N][Cout/16][H(/2)][W(/2)][16]
+    int N, H, W, Cin, Csc, Cout, KH, KW;
+    int relu, pool;
+};
+hipError_t launch_conv_mfma(hipStream_t s, const ConvMfmaArgs &a);
+
+// ------------------------------------------------------------------------------------------------ stems
+// First layers straight from the u8 blocks (Model_QBD.py:79-80, :130-135, :177-178, :228-233).
+// luma: block_y u8[N][68][68];  chroma: + block_u/v u8[N][34][34], plane 0 = 2x2 max-pool of block_y
+// (Inference_QBD.py:196-200).  msbd: adds the plane built from the raw QT logits q f32[N][8][8]
+// (nearest x8 / x4 upsample, zero pad top/left by 4 / 2).  Output: 32 channels, [N][2][S][S][16], S = 64 / 32.
+struct StemArgs {
+    const uint8_t *by, *bu, *bv;
+    const float *q;      // msbd only
+    const float *w;      // packed per conv: [conv][tap][cin][cout], see pack_stem()
+    const float *bias;   // [32]
+    float *out;
+    int N;
+};
+hipError_t launch_stem(hipStream_t s, bool luma, bool msbd, const StemArgs &a);
+
+// ------------------------------------------------------------------------------------------------ small direct conv
+// Generic direct convolution for the tiny tail layers (8x8 maps, 8-channel trunks):
+// out = [relu]( conv(x, w) [+ conv1x1(x_sc, w_sc)] [+ res] [+ bias] ).  Weights plain [tap][cin][cout_real].
+struct ConvDirectArgs {
+    const float *x; const float *w;
+    const float *x_sc; const float *w_sc;
+    const float *res; const float *bias;
+    float *out;
+    int N, H, W, Cin, CinPad, Csc, CscPad, Cout, CoutPad, KH, KW, relu;
+};
+hipError_t launch_conv_direct(hipStream_t s, const ConvDirectArgs &a);
+
+// Heads (Model_QBD.py:91,:139,:145-146,:152-153): 3x3, 8 -> 1 (QT) or 8 -> 2 (MTT layer k), bias, no activation.
+// QT: qt[n][y][x].  MTT layer k: bt[n][k][y][x] = ch0 (+ bt[n][k-1][y][x] if k > 0), dire[n][k][y][x] = ch1.
+struct HeadArgs {
+    const float *x;   // [N][1][S][S][16], channels 0..7 used
+    const float *w;   // [9][8][cout]
+    const float *bias;
+    float *qt, *bt, *dire;
+    int N, S, layer;  // layer < 0: QT head
+};
+hipError_t launch_head(hipStream_t s, const HeadArgs &a);
+
+// x5 [N][2][16][16][16] -> cat[x5, up2(mp2), up4(mp4), up8(mp8)] [N][8][16][16][16]  (Model_QBD.py:84-87)
+hipError_t launch_multipool_concat(hipStream_t s, const float *x5, float *x6, int N);
+
+// Attention trunk input (Model_QBD.py:140, :147): [N][1][S][S][16] with ch0 = up(q) (S/8 nearest), ch1 = bt[n][layer],
+// ch2 = dire[n][layer] (both 16x16, nearest-upsampled to S), channels 3..15 zero.
+hipError_t launch_att_input(hipStream_t s, const float *q, const float *bt, const float *dire, int layer, float *out,
+                            int N, int S);
+
+// 2x2 max-pool on a blocked activation (only used where the pool cannot ride a conv epilogue).
+hipError_t launch_maxpool2(hipStream_t s, const float *x, float *out, int N, int C, int H, int W);
+
+// ------------------------------------------------------------------------------------------------ post-processing
+// eli_structual_error + Map_to_Partition, one wavefront per block.  qt raw logits [N][64]; bt, dire [N][3][256].
+hipError_t launch_postprocess(hipStream_t s, const float *qt, const float *bt, const float *dire, int64_t N,
+                              int chroma_factor, uint8_t *hor, uint8_t *ver, uint8_t *qt_u8, int8_t *dire_i8);
+
+// Block cutter (Inference_QBD.py:104-149).
+hipError_t launch_cut_blocks(hipStream_t s, const void *y, const void *u, const void *v, int F, int H, int W,
+                             int bitdepth, uint8_t *by, uint8_t *bu, uint8_t *bv);
+
+}  // namespace pmp

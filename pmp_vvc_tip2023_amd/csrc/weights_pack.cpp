@@ -1,0 +1,198 @@
+// weights_pack.cpp — state_dict tensors (OIHW fp32, reference names) -> kernel layouts in device memory.
+//
+// Counterpart of load_pretrain_model (Inference_QBD.py:28-46): tensors are matched by name and shape; a missing or
+// mis-shaped tensor is an error (the reference silently keeps random init for such tensors, which would be a
+// silent accuracy bug here).
+#include <cstring>
+
+#include "pmp_host.h"
+
+namespace pmp {
+
+namespace {
+
+struct Blob {
+    const float *blob;
+    const pmp_tensor_desc *descs;
+    int ndesc;
+    const pmp_tensor_desc *find(const std::string &name) const
+    {
+        for (int i = 0; i < ndesc; ++i)
+            if (descs[i].name && name == descs[i].name) return &descs[i];
+        return nullptr;
+    }
+};
+
+int roundup16(int v) { return (v + 15) & ~15; }
+
+struct Uploader {
+    pmp_ctx *c;
+    NetWeights *nw;
+    int upload(const std::vector<float> &h, float **out)
+    {
+        void *d = nullptr;
+        hipError_t e = hipMalloc(&d, h.size() * sizeof(float));
+        if (e != hipSuccess) return hip_fail(c, e, "hipMalloc(weights)");
+        e = hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { hipFree(d); return hip_fail(c, e, "hipMemcpy(weights)"); }
+        nw->allocs.push_back(d);
+        *out = static_cast<float *>(d);
+        return PMP_OK;
+    }
+};
+
+// OIHW conv weight -> MFMA A-operand fragments [Cin_pad/16][KH*KW][Cout_pad/16][64 lanes][4]:
+// lane l of cout-tile nt holds W[cout = 16nt + (l&15)][channel = 16cb + 4(l>>4) + j], j = 0..3 (conv_mfma.hip).
+std::vector<float> pack_mfma(const float *w, int cout, int cin, int kh, int kw, int cout_pad, int cin_pad)
+{
+    const int taps = kh * kw, CB = cin_pad / 16, NT = cout_pad / 16;
+    std::vector<float> out((size_t)CB * taps * NT * 64 * 4, 0.f);
+    for (int cb = 0; cb < CB; ++cb)
+        for (int t = 0; t < taps; ++t)
+            for (int nt = 0; nt < NT; ++nt)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 4; ++j) {
+                        const int co = nt * 16 + (l & 15), ci = cb * 16 + 4 * (l >> 4) + j;
+                        float v = 0.f;
+                        if (co < cout && ci < cin) v = w[((size_t)co * cin + ci) * taps + t];
+                        out[((((size_t)cb * taps + t) * NT + nt) * 64 + l) * 4 + j] = v;
+                    }
+    return out;
+}
+
+// OIHW -> [tap][cin][cout] (direct kernels, stems, heads)
+std::vector<float> pack_plain(const float *w, int cout, int cin, int kh, int kw)
+{
+    const int taps = kh * kw;
+    std::vector<float> out((size_t)taps * cin * cout);
+    for (int t = 0; t < taps; ++t)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int co = 0; co < cout; ++co) out[((size_t)t * cin + ci) * cout + co] = w[((size_t)co * cin + ci) * taps + t];
+    return out;
+}
+
+int need(pmp_ctx *c, const Blob &b, const std::string &name, std::initializer_list<int> shape, const float **out)
+{
+    const pmp_tensor_desc *d = b.find(name);
+    if (!d) return set_err(c, PMP_E_INVALID, "weights: missing tensor " + name);
+    if (d->ndim != (int)shape.size()) return set_err(c, PMP_E_INVALID, "weights: wrong rank for " + name);
+    int i = 0;
+    for (int s : shape)
+        if (d->shape[i++] != s) return set_err(c, PMP_E_INVALID, "weights: wrong shape for " + name);
+    *out = b.blob + d->offset;
+    return PMP_OK;
+}
+
+int load_rb(pmp_ctx *c, const Blob &b, Uploader &up, const std::string &name, int cin, int cout, int k, bool direct)
+{
+    RBWeights r;
+    r.cin = cin; r.cout = cout; r.k = k; r.direct = direct;
+    r.cin_pad = roundup16(cin); r.cout_pad = roundup16(cout);
+    const float *w0, *w2, *wsc = nullptr;
+    int rc;
+    if ((rc = need(c, b, name + ".left.0.weight", {cout, cin, k, k}, &w0))) return rc;
+    if ((rc = need(c, b, name + ".left.2.weight", {cout, cout, k, k}, &w2))) return rc;
+    if (cin != cout && (rc = need(c, b, name + ".shortcut.0.weight", {cout, cin, 1, 1}, &wsc))) return rc;
+    if (direct) {
+        if ((rc = up.upload(pack_plain(w0, cout, cin, k, k), &r.w0))) return rc;
+        if ((rc = up.upload(pack_plain(w2, cout, cout, k, k), &r.w2))) return rc;
+        if (wsc && (rc = up.upload(pack_plain(wsc, cout, cin, 1, 1), &r.wsc))) return rc;
+    } else {
+        if ((rc = up.upload(pack_mfma(w0, cout, cin, k, k, r.cout_pad, r.cin_pad), &r.w0))) return rc;
+        if ((rc = up.upload(pack_mfma(w2, cout, cout, k, k, r.cout_pad, r.cout_pad), &r.w2))) return rc;
+        if (wsc && (rc = up.upload(pack_mfma(wsc, cout, cin, 1, 1, r.cout_pad, r.cin_pad), &r.wsc))) return rc;
+    }
+    up.nw->rb[name] = r;
+    return PMP_OK;
+}
+
+int load_head(pmp_ctx *c, const Blob &b, Uploader &up, const std::string &name, int cout, int slot)
+{
+    const float *w, *bias;
+    int rc;
+    if ((rc = need(c, b, name + ".weight", {cout, 8, 3, 3}, &w))) return rc;
+    if ((rc = need(c, b, name + ".bias", {cout}, &bias))) return rc;
+    if ((rc = up.upload(pack_plain(w, cout, 8, 3, 3), &up.nw->head_w[slot]))) return rc;
+    return up.upload(std::vector<float>(bias, bias + cout), &up.nw->head_b[slot]);
+}
+
+}  // namespace
+
+void free_net_weights(NetWeights &w)
+{
+    for (void *p : w.allocs) hipFree(p);
+    w = NetWeights();
+}
+
+int load_net_weights(pmp_ctx *c, int net_id, int qp, const float *blob, const pmp_tensor_desc *descs, int ndesc)
+{
+    if (net_id < 0 || net_id > 3 || !blob || !descs || ndesc <= 0) return set_err(c, PMP_E_INVALID, "pmp_load_weights: bad arguments");
+    const bool luma = net_id == PMP_NET_LUMA_Q || net_id == PMP_NET_LUMA_MSBD;
+    const bool msbd = net_id == PMP_NET_LUMA_MSBD || net_id == PMP_NET_CHROMA_MSBD;
+    Blob b{blob, descs, ndesc};
+    NetWeights nw;
+    Uploader up{c, &nw};
+    int rc = PMP_OK;
+    auto fail = [&](int code) { free_net_weights(nw); return code; };
+
+    if (!msbd) {
+        // Model_QBD.py:60-76 (luma) / :158-174 (chroma)
+        const int cin = luma ? 1 : 3, k1 = luma ? 9 : 5, kq = luma ? 5 : 3;
+        const float *w, *bias;
+        if ((rc = need(c, b, "conv_q1.weight", {32, cin, k1, k1}, &w))) return fail(rc);
+        if ((rc = need(c, b, "conv_q1.bias", {32}, &bias))) return fail(rc);
+        if ((rc = up.upload(pack_plain(w, 32, cin, k1, k1), &nw.stem_w))) return fail(rc);
+        if ((rc = up.upload(std::vector<float>(bias, bias + 32), &nw.stem_b))) return fail(rc);
+        if ((rc = load_rb(c, b, up, "resblock_q1", 32, 64, kq, false))) return fail(rc);
+        if ((rc = load_rb(c, b, up, "resblock_q2", 64, 64, kq, false))) return fail(rc);
+        if ((rc = load_rb(c, b, up, "resblock_q3", 64, 32, 3, false))) return fail(rc);
+        if ((rc = load_rb(c, b, up, "resblock_q4", 128, 32, 3, false))) return fail(rc);
+        if ((rc = load_rb(c, b, up, "resblock_q5", 32, 32, 3, false))) return fail(rc);
+        if ((rc = load_rb(c, b, up, "resblock_q6", 32, 8, 3, true))) return fail(rc);   // 8x8 map: direct kernel
+        if ((rc = load_head(c, b, up, "conv_q2", 1, 0))) return fail(rc);
+    } else {
+        // Model_QBD.py:101-125 (luma) / :199-223 (chroma)
+        const int cin = luma ? 2 : 4, k1 = luma ? 9 : 5, k2 = luma ? 5 : 3;
+        const float *w1, *w2, *w3, *b1, *b2, *b3;
+        if ((rc = need(c, b, "conv_b1_1.weight", {16, cin, k1, k1}, &w1))) return fail(rc);
+        if ((rc = need(c, b, "conv_b1_2.weight", {8, cin, k2, k1}, &w2))) return fail(rc);
+        if ((rc = need(c, b, "conv_b1_3.weight", {8, cin, k1, k2}, &w3))) return fail(rc);
+        if ((rc = need(c, b, "conv_b1_1.bias", {16}, &b1))) return fail(rc);
+        if ((rc = need(c, b, "conv_b1_2.bias", {8}, &b2))) return fail(rc);
+        if ((rc = need(c, b, "conv_b1_3.bias", {8}, &b3))) return fail(rc);
+        std::vector<float> sw = pack_plain(w1, 16, cin, k1, k1);
+        std::vector<float> t2 = pack_plain(w2, 8, cin, k2, k1), t3 = pack_plain(w3, 8, cin, k1, k2);
+        sw.insert(sw.end(), t2.begin(), t2.end());
+        sw.insert(sw.end(), t3.begin(), t3.end());
+        std::vector<float> sb(b1, b1 + 16);
+        sb.insert(sb.end(), b2, b2 + 8);
+        sb.insert(sb.end(), b3, b3 + 8);
+        if ((rc = up.upload(sw, &nw.stem_w))) return fail(rc);
+        if ((rc = up.upload(sb, &nw.stem_b))) return fail(rc);
+        if ((rc = load_rb(c, b, up, "trunk_M1.0", 32, 64, 5, false))) return fail(rc);
+        for (int i = 1; i < 6; ++i)
+            if ((rc = load_rb(c, b, up, "trunk_M1." + std::to_string(i), 64, 64, 3, false))) return fail(rc);
+        for (int i = 0; i < 4; ++i)
+            if ((rc = load_rb(c, b, up, "trunk_M2." + std::to_string(i), 64, 64, 3, false))) return fail(rc);
+        for (const char *t : {"trunk_B1", "trunk_B2", "trunk_B3"}) {
+            if ((rc = load_rb(c, b, up, std::string(t) + ".0", 64, 32, 3, false))) return fail(rc);
+            if ((rc = load_rb(c, b, up, std::string(t) + ".1", 32, 16, 3, false))) return fail(rc);
+            if ((rc = load_rb(c, b, up, std::string(t) + ".2", 16, 8, 3, false))) return fail(rc);
+        }
+        for (const char *t : {"trunk_Att1", "trunk_Att2"}) {
+            if ((rc = load_rb(c, b, up, std::string(t) + ".0", 3, 32, 3, false))) return fail(rc);
+            if ((rc = load_rb(c, b, up, std::string(t) + ".1", 32, 64, 3, false))) return fail(rc);
+        }
+        if ((rc = load_head(c, b, up, "conv_B1", 2, 0))) return fail(rc);
+        if ((rc = load_head(c, b, up, "conv_B2", 2, 1))) return fail(rc);
+        if ((rc = load_head(c, b, up, "conv_B3", 2, 2))) return fail(rc);
+    }
+    nw.loaded = true;
+    const int key = net_id * 100 + qp;
+    auto it = c->nets.find(key);
+    if (it != c->nets.end()) free_net_weights(it->second);
+    c->nets[key] = nw;
+    return PMP_OK;
+}
+
+}  // namespace pmp

@@ -1,0 +1,227 @@
+"""GPU parity tests: the HIP path through the C ABI against (a) golden vectors made by the imported reference and
+(b) the pinned oracle on the same seeded inputs.  Logits: 1e-3 absolute (north_star); integers: bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import g3_sets, golden, golden_path
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3  # north_star: "within 1e-3 fp32 on the map logits"
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from pmp_vvc_tip2023_amd import engine
+    e = engine.Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def g1():
+    return golden("g1_qt.npz")
+
+
+# ------------------------------------------------------------------------------------------------ nets
+@pytest.mark.parametrize("comp", ["Luma", "Chroma"])
+@pytest.mark.parametrize("qp", [22, 27, 32, 37])
+def test_qt_and_mtt_logits_vs_reference_golden(eng, g1, comp, qp):
+    """G1 (real QT weights) and G2 (synthetic MTT weights) through pmp_infer."""
+    g2 = golden("g2_msbd.npz")
+    qt, bt, dire = eng.inference_pre_QBD(comp, qp, g1["block_y"], g1["block_u"], g1["block_v"])
+    assert eng.provenance[(comp + "_Q", qp)].endswith(".pmpw")
+    assert qt.shape == (16, 1, 8, 8) and bt.shape == (16, 3, 16, 16)
+    eq = np.abs(qt - g1["qt_%s_%d" % (comp, qp)]).max()
+    assert eq < TOL, "QT logits off by %g" % eq
+    for k in range(3):
+        ref = g2["out%d_%s_%d" % (k, comp, qp)]           # [8,2,16,16] reference heads (ch0 depth, ch1 direction)
+        eb = np.abs(bt[:8, k] - ref[:, 0]).max()
+        ed = np.abs(dire[:8, k] - ref[:, 1]).max()
+        assert eb < TOL and ed < TOL, "MTT layer %d off by %g / %g" % (k, eb, ed)
+
+
+def test_config1_single_block_plumbing(eng, g1):
+    """BASELINE.json configs[0]: Luma QT-net QP22 on a single block."""
+    qt, _, _ = eng.inference_pre_QBD("Luma", 22, g1["block_y"][:1])
+    assert np.abs(qt - g1["qt_Luma_22"][:1]).max() < TOL
+
+
+@pytest.mark.parametrize("comp", ["Luma", "Chroma"])
+def test_logits_vs_oracle_fresh_inputs_and_chunking(eng, comp):
+    """Fresh seeded blocks: HIP vs the torch oracle; ragged chunking (chunk=5 over 13 blocks) is bit-identical
+    to one pass; extreme inputs (all 0, all 255) included."""
+    from oracle import nets_torch as O
+    from pmp_vvc_tip2023_amd import synth, weights as W
+    y, u, v = synth.recipe_r_blocks(13, 101)
+    y[0] = 0; u[0] = 0; v[0] = 0
+    y[1] = 255; u[1] = 255; v[1] = 255
+    luma = comp == "Luma"
+    qp = 27
+    qt, bt, dire = eng.inference_pre_QBD(comp, qp, y, u, v)
+    wq, _ = W.load_net_weights(comp + "_Q", qp)
+    wbd, _ = W.load_net_weights(comp + "_MSBD", qp)
+    x = O.luma_input(y) if luma else O.chroma_input(y, u, v)
+    oq, obt, odire = O.infer_qbd(wq, wbd, x, luma)
+    assert np.abs(qt - oq).max() < TOL and np.abs(bt - obt).max() < TOL and np.abs(dire - odire).max() < TOL
+    eng.set_chunk(5)
+    try:
+        qt2, bt2, dire2 = eng.inference_pre_QBD(comp, qp, y, u, v)
+    finally:
+        eng.set_chunk(512)
+    assert np.array_equal(qt, qt2) and np.array_equal(bt, bt2) and np.array_equal(dire, dire2)
+
+
+def test_caller_supplied_weights_and_errors(eng, g1):
+    from pmp_vvc_tip2023_amd import _lib, engine, synth
+    e2 = engine.Engine(0)
+    try:
+        with pytest.raises(_lib.PmpError) as ei:           # nothing loaded yet
+            e2._ck(e2.lib.pmp_infer(e2.h, 0, 22, None, None, None, 1, None, None, None))
+        assert ei.value.code == -1
+        w = synth.synth_msbd_weights("Luma", 22)
+        bad = dict(w); bad.pop("conv_B3.bias")
+        with pytest.raises(_lib.PmpError) as ei:
+            e2.load_pretrain_model("Luma_MSBD", 22, bad)
+        assert ei.value.code == -1 and "conv_B3.bias" in str(ei.value)
+        bad = dict(w); bad["trunk_M1.0.left.0.weight"] = np.zeros((64, 32, 3, 3), np.float32)
+        with pytest.raises(_lib.PmpError):
+            e2.load_pretrain_model("Luma_MSBD", 22, bad)
+        y = np.ascontiguousarray(g1["block_y"][:2])
+        qt = np.zeros((2, 64), np.float32); bt = np.zeros((2, 768), np.float32); dr = np.zeros((2, 768), np.float32)
+        rc = e2.lib.pmp_infer(e2.h, 0, 22, y.ctypes.data, None, None, 2, qt.ctypes.data, bt.ctypes.data, dr.ctypes.data)
+        assert rc == -3                                     # PMP_E_NOWEIGHTS
+        with pytest.raises(ValueError):
+            e2.inference_pre_QBD("Chroma", 22, y)           # chroma without u/v
+        # empty input
+        q0, b0, d0 = eng.inference_pre_QBD("Luma", 22, y[:0])
+        assert q0.shape == (0, 1, 8, 8) and b0.shape == (0, 3, 16, 16)
+    finally:
+        e2.close()
+
+
+# ------------------------------------------------------------------------------------------------ post-processing
+def test_map_to_partition_bit_exact_vs_reference_golden(eng, oracle_lib):
+    """G3 through pmp_postprocess.  The ABI applies eli_structual_error first (as seq_post_process does), so golden
+    outputs are compared where the fix is the identity on the fixture's QT map; the rest goes against the oracle."""
+    n_gold = n_oracle = 0
+    for tag, cf, qt, bt, dire, hor, ver, dout, leaves in g3_sets():
+        comp = "Luma" if cf == 1 else "Chroma"
+        h, v, q8, d8 = eng.post_process(qt, bt, dire, comp)
+        fixed = oracle_lib.eli_structural_error(qt).reshape(-1, 8, 8)
+        assert np.array_equal(q8, fixed.astype(np.uint8)), (tag, cf)
+        same = np.all(fixed == qt, axis=(1, 2))
+        assert np.array_equal(h[same], hor[same]) and np.array_equal(v[same], ver[same]) and np.array_equal(d8[same], dout[same]), (tag, cf)
+        n_gold += int(same.sum())
+        if (~same).any():
+            oh, ov, od, _ = oracle_lib.map_to_partition(fixed[~same], bt[~same], dire[~same], cf)
+            assert np.array_equal(h[~same], oh) and np.array_equal(v[~same], ov) and np.array_equal(d8[~same], od), (tag, cf)
+            n_oracle += int((~same).sum())
+    assert n_gold >= 900 and n_oracle > 0
+
+
+def test_eli_structural_error_bit_exact(eng):
+    g = golden("g4_eli.npz")
+    n = g["qt"].shape[0]
+    z = np.zeros((n, 3, 16, 16), np.float32)
+    _, _, q8, _ = eng.post_process(g["qt"], z, z, "Luma")
+    assert np.array_equal(q8.reshape(n, 1, 8, 8), g["out"].astype(np.uint8))
+
+
+@pytest.mark.parametrize("comp", ["Luma", "Chroma"])
+def test_seq_post_process_file_bytes(eng, comp, tmp_path):
+    """G5: reference seq_post_process output file, byte for byte."""
+    g = golden("g5_seq_%s.npz" % comp)
+    p = str(tmp_path / "o.txt")
+    eng.seq_post_process(g["qt"], g["bt"], g["dire"], comp, int(g["F"]), int(g["W"]), int(g["H"]), p)
+    assert open(p, "rb").read() == open(golden_path("g5_partitionmat_%s.txt" % comp), "rb").read()
+
+
+def test_postprocess_large_random_vs_oracle(eng, oracle_lib):
+    """20k fresh triples (valid partitions + noise, both chroma factors) against the pinned oracle."""
+    from pmp_vvc_tip2023_amd import synth
+    for cf, comp in ((1, "Luma"), (2, "Chroma")):
+        qt, bt, dire = synth.random_partition_batch(10000, 4242 + cf, cf, 0.2)
+        rng = np.random.default_rng(cf)
+        qt_logits = (qt + rng.normal(0, 0.3, qt.shape)).astype(np.float32)   # eli has real work to do
+        h, v, q8, d8 = eng.post_process(qt_logits, bt, dire, comp)
+        fixed = oracle_lib.eli_structural_error(qt_logits).reshape(-1, 8, 8)
+        oh, ov, od, _ = oracle_lib.map_to_partition(fixed, bt, dire, cf)
+        assert np.array_equal(q8, fixed.astype(np.uint8))
+        assert np.array_equal(h, oh) and np.array_equal(v, ov) and np.array_equal(d8, od)
+        assert h[:, 0, :].all() and v[:, :, 0].all()       # block top row / left column are always edges
+
+
+# ------------------------------------------------------------------------------------------------ cutter
+@pytest.mark.parametrize("bd", [8, 10])
+def test_block_cutter_vs_reference_golden(eng, bd):
+    g = golden("g6_cut.npz")
+    by, bu, bv = eng.output_block_yuv(g["y%d" % bd], g["u%d" % bd], g["v%d" % bd], bd)
+    assert np.array_equal(by, g["by%d" % bd]) and np.array_equal(bu, g["bu%d" % bd]) and np.array_equal(bv, g["bv%d" % bd])
+
+
+def test_block_cutter_1080p_vs_oracle(eng, oracle_lib):
+    from pmp_vvc_tip2023_amd import synth
+    y, u, v = synth.recipe_r_frames(1, 1080, 1920, 3, bitdepth=10)
+    by, bu, bv = eng.output_block_yuv(y, u, v, 10)
+    oy, ou, ov = oracle_lib.cut_blocks(y, u, v, 10)
+    assert by.shape == (480, 68, 68)                       # 30 x 16 blocks, bottom 56 rows dropped
+    assert np.array_equal(by, oy) and np.array_equal(bu, ou) and np.array_equal(bv, ov)
+    # tiny frame: fewer than 64 rows -> no blocks
+    e = eng.output_block_yuv(np.zeros((1, 32, 128), np.uint8), np.zeros((1, 16, 64), np.uint8), np.zeros((1, 16, 64), np.uint8), 8)
+    assert e[0].shape == (0, 68, 68)
+
+
+# ------------------------------------------------------------------------------------------------ full path, full size
+def test_config2_full_batch_properties(eng, oracle_lib):
+    """BASELINE.json configs[1] size (1024 luma blocks, QP22), device-resident fused path:
+    * fused infer+postprocess == postprocess(infer) bit for bit, and is deterministic across runs
+    * split flags are bit-exact against the oracle post-processing of the SAME device logits
+    * logits of a 24-block sample within 1e-3 of the torch oracle
+    * invariants of every valid partition (block borders are edges, QT map 2x2-constant, dire in {-1,0,1})."""
+    from oracle import nets_torch as O
+    from pmp_vvc_tip2023_amd import synth, weights as W
+    n = 1024
+    y, u, v = synth.recipe_r_blocks(n, 1)
+    eng.load("Luma", 22)
+    dev = torch.device("cuda:0")
+    d_y = torch.from_numpy(y).to(dev)
+    outs = []
+    for _ in range(2):
+        hor = torch.empty((n, 16, 16), dtype=torch.uint8, device=dev); ver = torch.empty_like(hor)
+        q8 = torch.empty((n, 8, 8), dtype=torch.uint8, device=dev); d8 = torch.empty((n, 3, 16, 16), dtype=torch.int8, device=dev)
+        qt = torch.empty((n, 1, 8, 8), device=dev); bt = torch.empty((n, 3, 16, 16), device=dev); dire = torch.empty_like(bt)
+        eng.infer_postprocess_device("Luma", 22, d_y.data_ptr(), None, None, n, hor.data_ptr(), ver.data_ptr(), q8.data_ptr(),
+                                     d8.data_ptr(), qt.data_ptr(), bt.data_ptr(), dire.data_ptr())
+        eng.synchronize()
+        outs.append([t.cpu().numpy() for t in (hor, ver, q8, d8, qt, bt, dire)])
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+    hor, ver, q8, d8, qt, bt, dire = outs[0]
+    h2, v2, q82, d82 = eng.post_process(qt, bt, dire, "Luma")
+    assert np.array_equal(hor, h2) and np.array_equal(ver, v2) and np.array_equal(q8, q82) and np.array_equal(d8, d82)
+    oh, ov, oq, od = oracle_lib.seq_post_process(qt, bt, dire, "Luma", 1, 64 * n, 64, None)
+    assert np.array_equal(hor, oh) and np.array_equal(ver, ov) and np.array_equal(d8, od) and np.array_equal(q8, oq.astype(np.uint8))
+    assert hor[:, 0, :].all() and ver[:, :, 0].all()
+    assert np.array_equal(q8[:, ::2, ::2], q8[:, 1::2, 1::2]) and q8.max() <= 3 and set(np.unique(d8)) <= {-1, 0, 1}
+    idx = np.arange(0, n, n // 24)[:24]
+    wq, _ = W.load_net_weights("Luma_Q", 22); wbd, _ = W.load_net_weights("Luma_MSBD", 22)
+    o_q, o_bt, o_dire = O.infer_qbd(wq, wbd, O.luma_input(y[idx]), True)
+    assert np.abs(qt[idx] - o_q).max() < TOL and np.abs(bt[idx] - o_bt).max() < TOL and np.abs(dire[idx] - o_dire).max() < TOL
+
+
+def test_config3_1080p_frame_all_qps(eng, oracle_lib, tmp_path):
+    """BASELINE.json configs[2]: one synthetic 1920x1080 frame -> 480 blocks, luma+chroma x 4 QPs; emitted file equals
+    the oracle's post-processing + writer on the same device logits, byte for byte."""
+    from pmp_vvc_tip2023_amd import synth
+    y, u, v = synth.recipe_r_frames(1, 1080, 1920, 3)
+    by, bu, bv = eng.output_block_yuv(y, u, v, 8)
+    for comp in ("Luma", "Chroma"):
+        for qp in (22, 27, 32, 37):
+            qt, bt, dire = eng.inference_pre_QBD(comp, qp, by, bu, bv)
+            p = str(tmp_path / ("%s_%d.txt" % (comp, qp)))
+            eng.seq_post_process(qt, bt, dire, comp, 1, 1920, 1080, p)
+            po = str(tmp_path / ("o_%s_%d.txt" % (comp, qp)))
+            oracle_lib.seq_post_process(qt, bt, dire, comp, 1, 1920, 1080, po)
+            a, b = open(p, "rb").read(), open(po, "rb").read()
+            assert a == b and a.count(b"\n") == 645120
