@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the partition-map prediction hot path on MI355X.
+
+One "step" = one pass of the device-resident hot path (QT-net + MTT-net inference + Map2Partition
+post-processing, pmp_infer_postprocess_device) over one batch of synthetic blocks already resident in HBM.
+Workload at every N: BASELINE.json configs[1] — Luma QT+MTT nets, QP22, batch = 1024 synthetic blocks per GPU
+(recipe R; QT weights real, MTT weights synthetic because the reference's *_BD_*.pkl are missing).
+Unit: the nets consume 64x64 blocks (+4 px context); one VTM CTU is 128x128 = 4 blocks, so
+CTU/s = blocks/s / 4.  `value` is CTU/s; blocks/s is reported next to it.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]        (N>1: launched by torch.distributed.run)
+
+Rank 0 prints ONE JSON line on stdout; diagnostics go to stderr.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+FLOP_PER_BLOCK = {"Luma": 6.991e9, "Chroma": 2.300e9}      # conv MACs x 2, QT + MTT
+PEAK_FP32_MFMA_TFLOPS = 157.3                                # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 peak
+DOMINANT = "conv_mfma_3x3_c64"                               # 3x3 64->64 convs: 57.8 % of the MTT-net FLOPs
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(sample_blocks, seed):
+    """The oracle (a port of the reference's torch CPU path + C post-processing) on this host's cores."""
+    from oracle import nets_torch as O, postproc as P
+    from pmp_vvc_tip2023_amd import synth, weights as W
+    ncpu = os.cpu_count() or 1
+    y, _, _ = synth.recipe_r_blocks(sample_blocks, seed)
+    wq, _ = W.load_net_weights("Luma_Q", 22)
+    wbd, _ = W.load_net_weights("Luma_MSBD", 22)
+    x = O.luma_input(y)
+    # torch's CPU convs do not scale to hundreds of threads on 64x64 maps: calibrate the thread count on 8 blocks
+    best = (None, 1e30)
+    for th in sorted({min(ncpu, t) for t in (8, 16, 32, 64, ncpu)}):
+        torch.set_num_threads(th)
+        O.infer_qbd(wq, wbd, x[:8], True, batch=8)           # warm-up (oneDNN primitive creation)
+        t = time.perf_counter()
+        O.infer_qbd(wq, wbd, x[:8], True, batch=8)
+        dt = time.perf_counter() - t
+        log("cpu_baseline: %3d threads -> %.1f blocks/s on 8 blocks" % (th, 8 / dt))
+        if dt < best[1]:
+            best = (th, dt)
+        if dt > 20:
+            break
+    cores = best[0]
+    torch.set_num_threads(cores)
+    sample_blocks = max(8, min(sample_blocks, int(20.0 / (best[1] / 8)) // 8 * 8))   # ~20 s of CPU work
+    x = x[:sample_blocks]
+    t0 = time.perf_counter()
+    qt, bt, dire = O.infer_qbd(wq, wbd, x, True, batch=64)
+    t1 = time.perf_counter()
+    P.seq_post_process(qt, bt, dire, "Luma", 1, 64 * sample_blocks, 64, None)
+    t2 = time.perf_counter()
+    log("cpu_baseline: nets %.2fs, post-proc %.3fs for %d blocks on %d threads" % (t1 - t0, t2 - t1, sample_blocks, cores))
+    return {"value": round(sample_blocks / 4.0 / (t2 - t0), 3), "unit": "CTU/s", "cores": cores, "kind": "port",
+            "blocks_per_s": round(sample_blocks / (t2 - t0), 2),
+            "sample": "%d luma blocks QP22 (recipe R seed %d): torch-CPU fp32 QT+MTT forward (batch 64, %d threads) + "
+                      "C oracle post-processing (1 thread)" % (sample_blocks, seed, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1024, help="blocks per GPU per step")
+    ap.add_argument("--comp", default="Luma", choices=["Luma", "Chroma"])
+    ap.add_argument("--qp", type=int, default=22)
+    ap.add_argument("--chunk", type=int, default=0, help="blocks per pass inside the library (0 = library default)")
+    ap.add_argument("--cpu-sample", type=int, default=512, help="blocks for the CPU baseline (0 = skip)")
+    ap.add_argument("--breakdown", action="store_true", help="extra pass with every kernel class timed (stderr)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        log("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
+    n_gpus = world if world > 1 else 1
+    if args.gpus > 1 and world == 1:
+        log("--gpus %d without torch.distributed.run: running the single-GPU workload" % args.gpus)
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if n_gpus > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from pmp_vvc_tip2023_amd import engine, synth
+    eng = engine.Engine(local_rank)
+    if args.chunk:
+        eng.set_chunk(args.chunk)
+    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    eng.load(args.comp, args.qp)
+    log("rank %d: weights %s" % (rank, {k[0]: v for k, v in eng.provenance.items()}))
+
+    n = args.batch
+    y, u, v = synth.recipe_r_blocks(n, 1 + rank)            # seed 1 on rank 0
+    d_y = torch.from_numpy(y).to(dev)
+    d_u = torch.from_numpy(u).to(dev)
+    d_v = torch.from_numpy(v).to(dev)
+    # one packed result record per block: hor[256] | ver[256] | qt[64] | dire[768] = 1344 bytes
+    res = torch.empty((n, 1344), dtype=torch.uint8, device=dev)
+    hor = torch.empty((n, 256), dtype=torch.uint8, device=dev); ver = torch.empty_like(hor)
+    q8 = torch.empty((n, 64), dtype=torch.uint8, device=dev); d8 = torch.empty((n, 768), dtype=torch.int8, device=dev)
+    gathered = torch.empty((world * n, 1344), dtype=torch.uint8, device=dev) if (n_gpus > 1 and rank == 0) else None
+    pu = d_u.data_ptr() if args.comp == "Chroma" else None
+    pv = d_v.data_ptr() if args.comp == "Chroma" else None
+
+    def step():
+        eng.infer_postprocess_device(args.comp, args.qp, d_y.data_ptr(), pu, pv, n, hor.data_ptr(), ver.data_ptr(),
+                                     q8.data_ptr(), d8.data_ptr())
+        if n_gpus > 1:
+            # the path's only exchange: split flags of every shard go to rank 0, which owns the file writer
+            res[:, :256] = hor; res[:, 256:512] = ver; res[:, 512:576] = q8; res[:, 576:] = d8.view(torch.uint8)
+            dist.gather(res, list(gathered.split(n)) if rank == 0 else None, dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    mask = 1 << [eng.lib.pmp_ktime_name(k).decode() for k in range(eng.lib.pmp_ktime_classes())].index(DOMINANT)
+    eng.ktime_enable(mask)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    kt = eng.ktime()
+    eng.ktime_enable(0)
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    blocks_per_s = n * n_gpus * args.steps / elapsed
+    launches, ms, flops = kt[DOMINANT]
+    roof = None
+    if launches:
+        achieved = flops / (ms * 1e-3) / 1e12
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.isfile(tp):
+            try:
+                traffic = json.load(open(tp)).get(DOMINANT)
+            except Exception:
+                traffic = None
+        roof = {"bound": "mfma", "kernel": DOMINANT, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                "launches": launches, "avg_launch_ms": round(ms / launches, 4),
+                "flop_per_launch": flops / launches}
+
+    if args.breakdown and rank == 0:
+        eng.ktime_enable(0xFFFF)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize(dev)
+        tot = 0.0
+        for k, (ln, kms, fl) in eng.ktime().items():
+            tot += kms
+            log("  %-20s launches %5d  %9.3f ms/step  %7.2f TFLOP/s" % (k, ln // 3, kms / 3, (fl / (kms * 1e-3) / 1e12) if kms else 0))
+        log("  sum of kernel time %.3f ms/step" % (tot / 3))
+        eng.ktime_enable(0)
+
+    if rank == 0:
+        out = {
+            "metric": "CTUs/sec (luma QT+MTT inference+post-proc)", "value": round(blocks_per_s / 4.0, 2), "unit": "CTU/s",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s QT+MTT nets QP%d, batch=%d synthetic 64x64 blocks (68x68 u8 inputs) per GPU, "
+                                   "device-resident infer+Map2Partition; CTU = 128x128 = 4 blocks" % (args.comp, args.qp, n),
+                       "blocks_per_gpu": n, "global_blocks": n * n_gpus, "parallelism": "dp%d (blocks sharded, gather of split flags to rank 0)" % n_gpus,
+                       "weights": "QT real (reference trained_models), MTT synthetic seed=qp"},
+            "blocks_per_s": round(blocks_per_s, 1),
+            "net_tflops": round(blocks_per_s * FLOP_PER_BLOCK[args.comp] / 1e12, 2),
+            "roofline": roof,
+        }
+        if args.cpu_sample > 0 and n_gpus == 1 and args.comp == "Luma":
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 1)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

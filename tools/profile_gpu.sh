@@ -1,0 +1,17 @@
+#!/bin/bash
+# Run ON THE GPU BOX (via gpurun) from the repo root: kernel-trace stats + separate PMC passes of bench.py.
+# Usage: tools/profile_gpu.sh <tag>   -> gpurun_out/prof_<tag>/
+set -u
+TAG=${1:-r01}
+OUT=$PWD/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+BENCH="python3 $PWD/bench.py --steps 3 --warmup 1 --cpu-sample 0"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
+# PMC passes (counters only; never combined with tracing).  SQ block has 8 slots, TCC 4 (FETCH_SIZE 3, WRITE_SIZE 2).
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- $BENCH > $OUT/pmc_sq.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1
+find $OUT -name "*.csv" | head -50
+ls -la $OUT
