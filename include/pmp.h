@@ -69,7 +69,7 @@ int pmp_destroy(pmp_ctx *ctx);
 int pmp_set_stream(pmp_ctx *ctx, void *hip_stream);
 int pmp_synchronize(pmp_ctx *ctx);
 
-/* Blocks processed per pass (activation workspace is sized for it); n > chunk is looped.  Default 512. */
+/* Blocks processed per pass (activation workspace is sized for it); n > chunk is looped.  Default 1024. */
 int pmp_set_chunk(pmp_ctx *ctx, int blocks);
 
 /* Caller keeps ownership of blob/descs; the library re-packs into its kernel layouts in device memory.
@@ -123,6 +123,11 @@ int pmp_ktime_classes(void);
 const char *pmp_ktime_name(int cls);
 /* Synchronises, then returns launches / total milliseconds / algorithmic FLOPs accumulated for the class. */
 int pmp_ktime_get(pmp_ctx *ctx, int cls, int64_t *launches, double *ms, double *flops);
+
+/* ---- measurement hook: selects the conv kernel build used by later launches (process-wide).
+ *      0 = un-pipelined kernel, 1 = software-pipelined (3 waves/SIMD), 2 = fully pipelined, 2 waves/SIMD (default).
+ *      Every variant computes bit-identical results; tools/conv_ab.py uses this for in-process A/B timing. ---- */
+int pmp_debug_set_conv_variant(int variant);
 
 #ifdef __cplusplus
 }

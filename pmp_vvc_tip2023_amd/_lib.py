@@ -47,6 +47,7 @@ SIGNATURES = {
     "pmp_ktime_classes": (_I, []),
     "pmp_ktime_name": (C.c_char_p, [_I]),
     "pmp_ktime_get": (_I, [_VP, _I, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "pmp_debug_set_conv_variant": (_I, [_I]),
 }
 
 _lib = None

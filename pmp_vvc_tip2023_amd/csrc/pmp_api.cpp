@@ -433,6 +433,13 @@ int pmp_write_partition_file(const char *path, int frames, int H, int W, const u
     return PMP_OK;
 }
 
+int pmp_debug_set_conv_variant(int variant)
+{
+    if (variant < 0 || variant > 2) return set_err(nullptr, PMP_E_INVALID, "pmp_debug_set_conv_variant: 0..2");
+    g_conv_variant = variant;
+    return PMP_OK;
+}
+
 // ---- timing ------------------------------------------------------------------------------------------------
 int pmp_ktime_classes(void) { return K_NCLASS; }
 

@@ -56,7 +56,7 @@ struct KTimeRec { hipEvent_t a, b; double flops; };
 struct pmp_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    int chunk = 512;
+    int chunk = 1024;
     std::string err;
     std::map<int, pmp::NetWeights> nets;  // key = net_id * 100 + qp
     pmp::Arena arena;

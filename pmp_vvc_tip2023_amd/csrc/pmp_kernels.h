@@ -25,6 +25,7 @@ struct ConvMfmaArgs {
     int relu, pool;
 };
 hipError_t launch_conv_mfma(hipStream_t s, const ConvMfmaArgs &a);
+extern int g_conv_variant;  // see pmp_debug_set_conv_variant
 
 // ------------------------------------------------------------------------------------------------ stems
 // First layers straight from the u8 blocks (Model_QBD.py:79-80, :130-135, :177-178, :228-233).

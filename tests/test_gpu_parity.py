@@ -68,7 +68,7 @@ def test_logits_vs_oracle_fresh_inputs_and_chunking(eng, comp):
     try:
         qt2, bt2, dire2 = eng.inference_pre_QBD(comp, qp, y, u, v)
     finally:
-        eng.set_chunk(512)
+        eng.set_chunk(1024)
     assert np.array_equal(qt, qt2) and np.array_equal(bt, bt2) and np.array_equal(dire, dire2)
 
 
