@@ -1,0 +1,207 @@
+"""Network inference + post-processing driver: drop-in for the reference's Inference_QBD.py.
+
+    python -m pmp_vvc_tip2023_amd.inference_qbd --jobID 0000 --inputDir /input/ --outDir /output/ \\
+           --batchSize 200 --startSeqID 0 --seqNum 22                     (Inference_QBD.py:257-267, same flags)
+    torchrun --nproc-per-node 8 -m pmp_vvc_tip2023_amd.inference_qbd ...  (blocks sharded over the GPUs)
+
+Output, byte-compatible with what the patched VTM-10.0 reads (EncAppCfg.cpp:4234-4404):
+    <outDir>/<jobID>/PartitionMat/<seq-file-stem>_<Luma|Chroma>_QP<22|27|32|37>_PartitionMat.txt   (:153,:237)
+    <outDir>/<jobID>/Time_Sta_<start>_<end>.txt    5 comma-terminated columns x 4 QP rows per sequence  (:243-253)
+
+Mirrors, function by function: load_sequences_info (:48-76), import_yuv420 (:78-102), output_block_yuv (:104-149,
+on the GPU), inference_VVC_seqs (:151-255).  Differences, all flags with the reference's values as defaults where
+the reference hard-codes them:
+  --seqTable   Training_Sequences.txt in the reference (:50, file not shipped); default VVC_Test_Sequences.txt
+  --cfgDir     ".\\per-sequence" (:162)                      --modelDir "./CTU_Models" (:219-220), falls back to weights/
+  --ssRatio    30 (:26); the codec demo uses TemporalSubsampleRatio 8 (encoder_intra_vtm.cfg:61)
+  sequence file stem: the reference's rstrip(".yuv") strips a character SET (:166); a real suffix strip is used
+  (identical for every name in VVC_Test_Sequences.txt and what EncAppCfg.cpp:4235-4242 expects).
+  Nets are loaded once per (component, QP) instead of once per sequence (:208-224).
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+from . import engine as E
+from . import parallel
+
+QPS = (22, 27, 32, 37)
+
+
+def load_sequences_info(seqs_info_path, ss_ratio, num=None):
+    """Inference_QBD.py:48-76: rows `name,file,W,H,frames,fps` until a line containing 'end!!!!'."""
+    data = []
+    with open(seqs_info_path, "r") as fp:
+        for line in fp:
+            if "end!!!!" in line:
+                break
+            line = line.rstrip("\n").strip()
+            if line:
+                data.append(line.split(","))
+    if num is not None:
+        data = data[:num]
+    names = [d[0] for d in data]
+    files = [d[1] for d in data]
+    width = [int(d[2]) for d in data]
+    height = [int(d[3]) for d in data]
+    frames = [int(d[4]) for d in data]
+    sub = [(f + ss_ratio - 1) // ss_ratio for f in frames]
+    blocks = [(w // 64) * (h // 64) * s for w, h, s in zip(width, height, sub)]
+    return names, files, width, height, frames, sub, blocks
+
+
+def parse_seq_cfg(path):
+    """Inference_QBD.py:171-186: InputFile and InputBitDepth from a VTM per-sequence cfg ('#' starts a comment)."""
+    seq_path, is10bit = None, False
+    with open(path) as fp:
+        for line in fp:
+            if "InputFile" in line:
+                line = line.rstrip("\n").split("#")[0].replace(" ", "")
+                seq_path = line.split(":", 1)[1]
+            elif "InputBitDepth" in line:
+                line = line.rstrip("\n").split("#")[0].replace(" ", "")
+                is10bit = line.split(":", 1)[1] == "10"
+    if seq_path is None:
+        raise ValueError("%s: no InputFile entry" % path)
+    return seq_path, is10bit
+
+
+def import_yuv420(file_path, width, height, frm_num, SubSampleRatio=1, is10bit=False):
+    """Inference_QBD.py:78-102: every SubSampleRatio-th frame of a planar 4:2:0 file -> y[F,H,W], u,v[F,H/2,W/2]."""
+    pix = width * height
+    sub = (frm_num + SubSampleRatio - 1) // SubSampleRatio
+    dt = np.uint16 if is10bit else np.uint8
+    y = np.zeros((sub, height, width), dt); u = np.zeros((sub, height // 2, width // 2), dt); v = np.zeros_like(u)
+    with open(file_path, "rb") as fp:
+        for i in range(0, frm_num, SubSampleRatio):
+            fp.seek(i * pix * 3 if is10bit else i * pix * 3 // 2, 0)
+            k = i // SubSampleRatio
+            y[k] = np.fromfile(fp, dtype=dt, count=pix).reshape(height, width)
+            u[k] = np.fromfile(fp, dtype=dt, count=pix // 4).reshape(height // 2, width // 2)
+            v[k] = np.fromfile(fp, dtype=dt, count=pix // 4).reshape(height // 2, width // 2)
+    return y, u, v
+
+
+def strip_yuv_suffix(name):
+    return name[:-4] if name.endswith(".yuv") else name
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    p.add_argument("--jobID", type=str, default="0000")
+    p.add_argument("--inputDir", type=str, default="/input/")
+    p.add_argument("--outDir", type=str, default="/output/")
+    p.add_argument("--batchSize", default=200, type=int, help="blocks per forward pass (library chunk)")
+    p.add_argument("--startSeqID", default=0, type=int)
+    p.add_argument("--seqNum", default=22, type=int)
+    # paths the reference hard-codes
+    p.add_argument("--seqTable", default="VVC_Test_Sequences.txt")
+    p.add_argument("--cfgDir", default=os.path.join(".", "per-sequence"))
+    p.add_argument("--modelDir", default="./CTU_Models")
+    p.add_argument("--ssRatio", default=30, type=int, help="temporal sub-sampling (Inference_QBD.py:26)")
+    p.add_argument("--qps", default="22,27,32,37")
+    p.add_argument("--comps", default="Luma,Chroma")
+    p.add_argument("--device", default=None, type=int, help="GPU index (default: LOCAL_RANK)")
+    return p
+
+
+def _resolve(path, base):
+    return path if os.path.isabs(path) or os.path.exists(path) else os.path.join(base, path)
+
+
+def inference_VVC_seqs(args):
+    """Inference_QBD.py:151-255."""
+    rank, world, local = parallel.env_world()
+    dev_id = args.device if args.device is not None else local
+    eng = E.Engine(dev_id, weight_dir=args.modelDir if os.path.isdir(args.modelDir) else None)
+    eng.set_chunk(max(1, args.batchSize))
+    device = None
+    if world > 1:
+        import torch
+        device = torch.device("cuda", dev_id)
+        torch.cuda.set_device(device)
+    parallel.init_process_group(device)
+
+    save_dir = os.path.join(args.outDir, args.jobID, "PartitionMat")
+    if rank == 0:
+        os.makedirs(save_dir, exist_ok=True)
+    qps = [int(q) for q in args.qps.split(",") if q]
+    comps = [c for c in args.comps.split(",") if c]
+
+    names, files, widths, heights, frames, sub_frames, _ = load_sequences_info(_resolve(args.seqTable, args.inputDir), args.ssRatio)
+    end = min(args.startSeqID + args.seqNum, len(names))
+    nseq = max(0, end - args.startSeqID)
+    seqs_block_time = np.zeros(max(nseq, 1))
+    seqs_net_time = np.zeros((max(nseq, 1), 4, 2))
+    seqs_post_time = np.zeros((max(nseq, 1), 4, 2))
+
+    for comp in comps:  # weights once per (comp, qp), not once per sequence
+        for qp in qps:
+            eng.load(comp, qp)
+
+    for si, seq_id in enumerate(range(args.startSeqID, end)):
+        seq_name, stem = names[seq_id], strip_yuv_suffix(files[seq_id])
+        width, height, numfrm, sub_numfrm = widths[seq_id], heights[seq_id], frames[seq_id], sub_frames[seq_id]
+        seq_path, is10bit = parse_seq_cfg(os.path.join(args.cfgDir, seq_name + ".cfg"))
+        seq_path = _resolve(seq_path, args.inputDir)
+        if rank == 0:
+            print(seq_name, flush=True)
+        # ---- load input blocks: every rank cuts only the frames of its own block range
+        t0 = time.time()
+        y, u, v = import_yuv420(seq_path, width, height, numfrm, args.ssRatio, is10bit)
+        per_frame = (width // 64) * (height // 64)
+        n_total = per_frame * sub_numfrm
+        lo, hi = parallel.shard_bounds(n_total, rank, world)
+        if hi > lo and per_frame:
+            f0, f1 = lo // per_frame, (hi + per_frame - 1) // per_frame
+            by, bu, bv = eng.output_block_yuv(y[f0:f1], u[f0:f1], v[f0:f1], 10 if is10bit else 8)
+            by, bu, bv = (a[lo - f0 * per_frame:hi - f0 * per_frame] for a in (by, bu, bv))
+        else:
+            by = np.zeros((0, 68, 68), np.uint8); bu = np.zeros((0, 34, 34), np.uint8); bv = np.zeros((0, 34, 34), np.uint8)
+        seqs_block_time[si] = time.time() - t0
+
+        for comp_id, comp in enumerate(comps):
+            for qp in qps:
+                qi = (qp - 22) // 5 if qp in QPS else 0
+                t0 = time.time()
+                hor, ver, q8, d8 = eng.infer_postprocess(comp, qp, by, bu, bv)
+                seqs_net_time[si, qi, comp_id] = time.time() - t0
+                t0 = time.time()
+                rec = parallel.gather_records(parallel.pack_records(hor, ver, q8, d8), n_total, device)
+                if rank == 0:
+                    h, vv, q, d = parallel.unpack_records(rec)
+                    save_path = os.path.join(save_dir, "%s_%s_QP%d_PartitionMat.txt" % (stem, comp, qp))
+                    print("Save:", save_path, flush=True)
+                    E.write_partition_file(save_path, sub_numfrm, height, width, h, vv, q, d)
+                seqs_post_time[si, qi, comp_id] = time.time() - t0
+
+    if rank == 0:  # Time_Sta log, Inference_QBD.py:243-253 (net column = inference + GPU post-processing here)
+        sta = os.path.join(args.outDir, args.jobID, "Time_Sta_%d_%d.txt" % (args.startSeqID, args.startSeqID + args.seqNum))
+        with open(sta, "w") as fp:
+            for si in range(nseq):
+                for qp_id in range(4):
+                    for s in (seqs_block_time[si], seqs_net_time[si, qp_id, 0], seqs_net_time[si, qp_id, 1],
+                              seqs_post_time[si, qp_id, 0], seqs_post_time[si, qp_id, 1]):
+                        fp.write(str(s))
+                        fp.write(",")
+                    fp.write("\n")
+        print("Sum time:", np.sum(seqs_block_time) + np.sum(seqs_net_time) + np.sum(seqs_post_time))
+    eng.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    t0 = time.time()
+    inference_VVC_seqs(args)
+    print("Total inference time:", time.time() - t0)
+
+
+if __name__ == "__main__":
+    main()

@@ -225,3 +225,43 @@ def test_config3_1080p_frame_all_qps(eng, oracle_lib, tmp_path):
             oracle_lib.seq_post_process(qt, bt, dire, comp, 1, 1920, 1080, po)
             a, b = open(p, "rb").read(), open(po, "rb").read()
             assert a == b and a.count(b"\n") == 645120
+
+
+# ------------------------------------------------------------------------------------------------ driver end to end
+def test_driver_end_to_end_files(eng, oracle_lib, tmp_path):
+    """The CLI driver on two tiny synthetic sequences (8-bit 192x128 and 10-bit 136x72, temporal sub-sampling 2):
+    every emitted PartitionMat file equals oracle(cutter) -> HIP logits -> oracle(post-processing + writer), and
+    the Time_Sta log has the reference's shape (Inference_QBD.py:243-253)."""
+    import os
+    from pmp_vvc_tip2023_amd import inference_qbd as D, synth
+    inp = tmp_path / "in"; out = tmp_path / "out"; cfg = tmp_path / "cfg"
+    inp.mkdir(); cfg.mkdir()
+    seqs = [("SeqA", "SeqA_192x128_30.yuv", 192, 128, 3, 8), ("SeqB", "SeqB_136x72_30.yuv", 136, 72, 4, 10)]
+    with open(inp / "table.txt", "w") as f:
+        for name, fn, w, h, fr, bd in seqs:
+            f.write("%s,%s,%d,%d,%d,30\n" % (name, fn, w, h, fr))
+        f.write("#end!!!!\n")
+    planes = {}
+    for k, (name, fn, w, h, fr, bd) in enumerate(seqs):
+        y, u, v = synth.recipe_r_frames(fr, h, w, 70 + k, bitdepth=bd)
+        planes[name] = (y, u, v)
+        with open(inp / fn, "wb") as f:
+            for i in range(fr):
+                f.write(y[i].tobytes()); f.write(u[i].tobytes()); f.write(v[i].tobytes())
+        with open(cfg / (name + ".cfg"), "w") as f:
+            f.write("InputFile                     : %s   # comment\nInputBitDepth                 : %d\n" % (fn, bd))
+    D.main(["--jobID", "j1", "--inputDir", str(inp), "--outDir", str(out), "--seqTable", "table.txt", "--cfgDir", str(cfg),
+            "--ssRatio", "2", "--startSeqID", "0", "--seqNum", "2", "--batchSize", "5", "--qps", "22,37"])
+    for name, fn, w, h, fr, bd in seqs:
+        y, u, v = planes[name]
+        by, bu, bv = oracle_lib.cut_blocks(y[::2], u[::2], v[::2], bd)
+        nf = (fr + 1) // 2
+        for comp in ("Luma", "Chroma"):
+            for qp in (22, 37):
+                qt, bt, dire = eng.inference_pre_QBD(comp, qp, by, bu, bv)
+                po = str(tmp_path / "o.txt")
+                oracle_lib.seq_post_process(qt, bt, dire, comp, nf, w, h, po)
+                got = out / "j1" / "PartitionMat" / ("%s_%s_QP%d_PartitionMat.txt" % (fn[:-4], comp, qp))
+                assert open(got, "rb").read() == open(po, "rb").read(), (name, comp, qp)
+    rows = open(out / "j1" / "Time_Sta_0_2.txt").read().strip().split("\n")
+    assert len(rows) == 2 * 4 and all(r.count(",") == 5 for r in rows)

@@ -1,0 +1,77 @@
+"""CPU, world_size 2 over gloo: the N>1 path (shard -> per-rank post-processing -> gather to rank 0 -> file).
+The per-rank compute is stood in by the oracle (the HIP path needs a GPU); what is under test is the sharding,
+record packing, the gather collective and that rank 0's file equals the single-process file."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden, golden_path
+from pmp_vvc_tip2023_amd import parallel
+
+
+def test_shard_bounds_cover_and_order():
+    for n in (0, 1, 7, 480, 1980, 1024):
+        for world in (1, 2, 3, 8):
+            prev = 0
+            for r in range(world):
+                lo, hi = parallel.shard_bounds(n, r, world)
+                assert lo == prev and hi >= lo
+                prev = hi
+            assert prev == n
+            c = parallel.shard_counts(n, world)
+            assert sum(c) == n and max(c) - min(c) <= 1
+    with pytest.raises(ValueError):
+        parallel.shard_bounds(4, 2, 2)
+
+
+def test_record_round_trip():
+    rng = np.random.default_rng(0)
+    hor = rng.integers(0, 2, (5, 16, 16)).astype(np.uint8); ver = rng.integers(0, 2, (5, 16, 16)).astype(np.uint8)
+    q8 = rng.integers(0, 4, (5, 8, 8)).astype(np.uint8); d8 = rng.integers(-1, 2, (5, 3, 16, 16)).astype(np.int8)
+    rec = parallel.pack_records(hor, ver, q8, d8)
+    assert rec.shape == (5, 1344)
+    h, v, q, d = parallel.unpack_records(rec)
+    assert np.array_equal(h, hor) and np.array_equal(v, ver) and np.array_equal(q, q8) and np.array_equal(d, d8)
+
+
+WORKER = textwrap.dedent('''
+    import os, sys
+    sys.path.insert(0, %(root)r)
+    import numpy as np
+    from pmp_vvc_tip2023_amd import parallel, engine
+    from oracle import postproc as P
+    rank, world, _ = parallel.init_process_group(None)
+    g = np.load(%(npz)r)
+    qt, bt, dire = g["qt"], g["bt"], g["dire"]
+    n = qt.shape[0]
+    lo, hi = parallel.shard_bounds(n, rank, world)
+    hor, ver, q, d = P.seq_post_process(qt[lo:hi], bt[lo:hi], dire[lo:hi], "Luma", 1, 64 * (hi - lo), 64, None)
+    rec = parallel.gather_records(parallel.pack_records(hor, ver, q.astype(np.uint8), d), n)
+    if rank == 0:
+        h, v, q8, d8 = parallel.unpack_records(rec)
+        engine.write_partition_file(%(out)r, int(g["F"]), int(g["H"]), int(g["W"]), h, v, q8, d8)
+    else:
+        assert rec is None
+    import torch.distributed as dist
+    dist.barrier(); dist.destroy_process_group()
+''')
+
+
+def test_two_rank_gloo_gather_matches_single_process(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "out.txt")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT, "npz": golden_path("g5_seq_Luma.npz"), "out": out})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    logs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\\n".join(logs)
+    assert open(out, "rb").read() == open(golden_path("g5_partitionmat_Luma.txt"), "rb").read()
