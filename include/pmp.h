@@ -72,6 +72,14 @@ int pmp_synchronize(pmp_ctx *ctx);
 /* Blocks processed per pass (activation workspace is sized for it); n > chunk is looped.  Default 1024. */
 int pmp_set_chunk(pmp_ctx *ctx, int blocks);
 
+/* Convolution datapath.  Both are fp32-accurate; results differ in the last bits only.
+ *   PMP_PRECISION_F32    v_mfma_f32_16x16x4_f32, exact fp32 fmaf chain
+ *   PMP_PRECISION_BF16X6 (default) every fp32 operand carried as 3 bf16 terms, 6 bf16 MFMA products, fp32 accumulate */
+#define PMP_PRECISION_F32 0
+#define PMP_PRECISION_BF16X6 1
+int pmp_set_precision(pmp_ctx *ctx, int mode);
+int pmp_get_precision(const pmp_ctx *ctx);
+
 /* Caller keeps ownership of blob/descs; the library re-packs into its kernel layouts in device memory.
  * Every tensor the net needs must be present with the reference's shape (else PMP_E_INVALID). */
 int pmp_load_weights(pmp_ctx *ctx, int net_id, int qp, const float *blob, const pmp_tensor_desc *descs,
@@ -128,6 +136,12 @@ int pmp_ktime_get(pmp_ctx *ctx, int cls, int64_t *launches, double *ms, double *
  *      0 = un-pipelined kernel, 1 = software-pipelined (3 waves/SIMD), 2 = fully pipelined, 2 waves/SIMD (default).
  *      Every variant computes bit-identical results; tools/conv_ab.py uses this for in-process A/B timing. ---- */
 int pmp_debug_set_conv_variant(int variant);
+
+/* ---- measurement hook: one convolution layer on random data, both datapaths.  Runs conv KxK Cin->Cout (+ReLU) on
+ *      n blocks of HxW with the fp32-MFMA kernel and with the bf16x6 split kernel, `iters` timed launches each.
+ *      Outputs: average milliseconds per launch and max |fp32 - bf16x6| / max |fp32| over the whole output. ---- */
+int pmp_debug_conv_bench(pmp_ctx *ctx, int n, int h, int w, int cin, int cout, int k, int iters, double *ms_f32,
+                         double *ms_x6, double *max_abs_diff, double *max_abs_ref);
 
 #ifdef __cplusplus
 }

@@ -31,6 +31,8 @@ SIGNATURES = {
     "pmp_set_stream": (_I, [_VP, _VP]),
     "pmp_synchronize": (_I, [_VP]),
     "pmp_set_chunk": (_I, [_VP, _I]),
+    "pmp_set_precision": (_I, [_VP, _I]),
+    "pmp_get_precision": (_I, [_VP]),
     "pmp_load_weights": (_I, [_VP, _I, _I, _VP, C.POINTER(TensorDesc), _I]),
     "pmp_has_weights": (_I, [_VP, _I, _I]),
     "pmp_infer": (_I, [_VP, _I, _I, _VP, _VP, _VP, _I64, _VP, _VP, _VP]),
@@ -48,6 +50,7 @@ SIGNATURES = {
     "pmp_ktime_name": (C.c_char_p, [_I]),
     "pmp_ktime_get": (_I, [_VP, _I, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pmp_debug_set_conv_variant": (_I, [_I]),
+    "pmp_debug_conv_bench": (_I, [_VP, _I, _I, _I, _I, _I, _I, _I] + [C.POINTER(C.c_double)] * 4),
 }
 
 _lib = None

@@ -1,0 +1,286 @@
+// conv_bf16x6.hip — fp32-accurate convolution on the bf16 matrix cores by 3-term operand splitting.
+//
+// Every fp32 value v is carried as three bf16 values v = v0 + v1 + v2 (exact: 3 x 8 significand bits = 24).
+// A product x*w is evaluated as the six bf16 MFMA products with weight >= 2^-16:
+//      x0w0 + (x0w1 + x1w0) + (x0w2 + x1w1 + x2w0)            (dropped terms are <= 2^-24 relative)
+// accumulated in the MFMA's fp32 accumulator.  tools/precision_study.py: on the real Luma_Q_22 net this is as
+// close to the reference as fp32 arithmetic itself (9.2e-5 vs 8.2e-5 for fp64-vs-fp32), while the 3-product split
+// (4.6e-3) and single bf16 (0.79) break the 1e-3 tolerance.  Six v_mfma_f32_16x16x32_bf16 (16 cycles, K=32) replace
+// sixteen v_mfma_f32_16x16x4_f32 (32 cycles, K=4 each) per 32 channels: 2.67x the fp32-MFMA peak.
+//
+// Activation format ("split-3"): three bf16 planes, each blocked channels-last [n][C/16][H][W][16] (32 B per pixel and
+// group), plane stride = N*C*H*W elements.  Same bytes-per-lane coalescing as the fp32 layout: 16 pixels x 32 B = 512 B
+// contiguous per plane per tile row.
+//
+// GEMM mapping: D[cout][pixel], A = weights, B = pixels (as conv_mfma.hip).  One MFMA K-step (K = 32) covers
+// 16 channels x a PAIR of taps: lane group g = l>>4 reads channels 8(g&1)..+7 of tap 2p+(g>>1).  An odd tap count pads
+// the last pair with zero weights (3x3: 10 % padding, 5x5: 4 %).
+#include "pmp_kernels.h"
+
+namespace pmp {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3(float v, __bf16 &a, __bf16 &b, __bf16 &c)
+{
+    a = (__bf16)v;
+    const float r1 = v - (float)a;   // exact
+    b = (__bf16)r1;
+    const float r2 = r1 - (float)b;  // exact
+    c = (__bf16)r2;                  // exact: at most 8 significant bits are left
+}
+
+template <int KH, int KW>
+struct GeoX {
+    static constexpr int TH = 16 + KH - 1, TW = 16 + KW - 1, TAPS = KH * KW, NKS = (TAPS + 1) / 2;
+    static constexpr int PLANE = TH * TW * 2;            // 16-B pieces per split plane (32 B per pixel)
+    static constexpr int PIECES = 3 * PLANE;             // per buffer
+    static constexpr int NLD = (PIECES + 255) / 256;
+};
+
+// global -> registers: unconditional loads (clamped coordinates) so hipcc can count them (see conv_mfma.hip)
+template <int KH, int KW>
+__device__ __forceinline__ void x6_stage_load(const unsigned short *__restrict__ grp, size_t plane_stride, int H, int W,
+                                              int ty, int tx, u32x4 (&r)[GeoX<KH, KW>::NLD])
+{
+    typedef GeoX<KH, KW> G;
+    constexpr int PY = KH / 2, PX = KW / 2;
+#pragma unroll
+    for (int k = 0; k < G::NLD; ++k) {
+        const int i = min((int)threadIdx.x + k * 256, G::PIECES - 1);
+        const int sp = i / G::PLANE, j = i - sp * G::PLANE, pix = j >> 1, half = j & 1;
+        const int row = pix / G::TW, col = pix - row * G::TW;
+        const int gy = min(max(ty * 16 + row - PY, 0), H - 1), gx = min(max(tx * 16 + col - PX, 0), W - 1);
+        r[k] = *reinterpret_cast<const u32x4 *>(grp + sp * plane_stride + ((size_t)gy * W + gx) * 16 + half * 8);
+    }
+}
+
+template <int KH, int KW>
+__device__ __forceinline__ void x6_stage_store(u32x4 *lds, const u32x4 (&r)[GeoX<KH, KW>::NLD], int H, int W, int ty, int tx)
+{
+    typedef GeoX<KH, KW> G;
+    constexpr int PY = KH / 2, PX = KW / 2;
+#pragma unroll
+    for (int k = 0; k < G::NLD; ++k) {
+        const int i = threadIdx.x + k * 256;
+        const int sp = i / G::PLANE, j = i - sp * G::PLANE, pix = j >> 1;
+        const int row = pix / G::TW, col = pix - row * G::TW;
+        const int gy = ty * 16 + row - PY, gx = tx * 16 + col - PX;
+        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        if (i < G::PIECES) lds[i] = in ? r[k] : z;   // LDS image: [split][pixel][2 halves] 16-B pieces, linear
+    }
+}
+
+template <int KH, int KW, int NT>
+__device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__ x, size_t plane_stride,
+                                              const unsigned short *__restrict__ wpk, int C, int H, int W, int n, int ty,
+                                              int tx, u32x4 *lds, f32x4 (&acc)[4][NT])
+{
+    typedef GeoX<KH, KW> G;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, xl = lane & 15, g = lane >> 4;
+    const int CB = C >> 4;
+    const size_t grp_sz = (size_t)H * W * 16;
+    const unsigned short *grp0 = x + (size_t)n * CB * grp_sz;
+    u32x4 r[G::NLD];
+    __syncthreads();
+    x6_stage_load<KH, KW>(grp0, plane_stride, H, W, ty, tx, r);
+    x6_stage_store<KH, KW>(lds, r, H, W, ty, tx);
+    __syncthreads();
+    // weights: [cb][ks][split][nt][lane] 16-B fragments
+    const bf16x8 *wl = reinterpret_cast<const bf16x8 *>(wpk) + lane;
+    for (int cb = 0; cb < CB; ++cb) {
+        const bool more = cb + 1 < CB;
+        if (more) x6_stage_load<KH, KW>(grp0 + (size_t)(cb + 1) * grp_sz, plane_stride, H, W, ty, tx, r);
+        const char *buf = reinterpret_cast<const char *>(lds + (cb & 1) * G::PIECES);
+#pragma unroll
+        for (int ks = 0; ks < G::NKS; ++ks) {
+            // this lane's tap of the pair
+            constexpr int dummy = 0; (void)dummy;
+            const int t0 = 2 * ks, t1 = (2 * ks + 1 < G::TAPS) ? 2 * ks + 1 : 2 * ks;
+            const int dy0 = t0 / KW, dx0 = t0 % KW, dy1 = t1 / KW, dx1 = t1 % KW;
+            const int dy = (g >> 1) ? dy1 : dy0, dx = (g >> 1) ? dx1 : dx0;
+            const int pbase = (((wave * 4 + dy) * G::TW + xl + dx) * 2 + (g & 1)) * 16;   // bytes inside a split plane
+            const bf16x8 *wk = wl + ((size_t)(cb * G::NKS + ks) * 3 * NT) * 64;
+            bf16x8 wf[3][NT];
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) wf[s][nt] = wk[(s * NT + nt) * 64];
+            bf16x8 xf[4];
+            // x0 with w0, w1, w2
+#pragma unroll
+            for (int m = 0; m < 4; ++m) xf[m] = *reinterpret_cast<const bf16x8 *>(buf + pbase + m * G::TW * 32);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2][nt], xf[m], acc[m][nt], 0, 0, 0);
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][nt], xf[m], acc[m][nt], 0, 0, 0);
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][nt], xf[m], acc[m][nt], 0, 0, 0);
+                }
+            // x1 with w0, w1
+#pragma unroll
+            for (int m = 0; m < 4; ++m) xf[m] = *reinterpret_cast<const bf16x8 *>(buf + G::PLANE * 16 + pbase + m * G::TW * 32);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][nt], xf[m], acc[m][nt], 0, 0, 0);
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][nt], xf[m], acc[m][nt], 0, 0, 0);
+                }
+            // x2 with w0
+#pragma unroll
+            for (int m = 0; m < 4; ++m) xf[m] = *reinterpret_cast<const bf16x8 *>(buf + 2 * G::PLANE * 16 + pbase + m * G::TW * 32);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][nt], xf[m], acc[m][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) x6_stage_store<KH, KW>(lds + ((cb + 1) & 1) * G::PIECES, r, H, W, ty, tx);
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ f32x4 load_split4(const unsigned short *p, size_t plane_stride)
+{
+    // 4 consecutive channels of one pixel from the three planes, summed exactly back to fp32
+    const bf16x4 a = *reinterpret_cast<const bf16x4 *>(p), b = *reinterpret_cast<const bf16x4 *>(p + plane_stride),
+                 c = *reinterpret_cast<const bf16x4 *>(p + 2 * plane_stride);
+    f32x4 v;
+    v.x = ((float)a.x + (float)b.x) + (float)c.x; v.y = ((float)a.y + (float)b.y) + (float)c.y;
+    v.z = ((float)a.z + (float)b.z) + (float)c.z; v.w = ((float)a.w + (float)b.w) + (float)c.w;
+    return v;
+}
+
+__device__ __forceinline__ void store_split4(unsigned short *p, size_t plane_stride, f32x4 v)
+{
+    __bf16 a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3;
+    split3(v.x, a0, b0, c0); split3(v.y, a1, b1, c1); split3(v.z, a2, b2, c2); split3(v.w, a3, b3, c3);
+    const bf16x4 a = {a0, a1, a2, a3}, b = {b0, b1, b2, b3}, c = {c0, c1, c2, c3};
+    *reinterpret_cast<bf16x4 *>(p) = a;
+    *reinterpret_cast<bf16x4 *>(p + plane_stride) = b;
+    *reinterpret_cast<bf16x4 *>(p + 2 * plane_stride) = c;
+}
+
+template <int KH, int KW, int NT>
+__global__ __launch_bounds__(256, 2) void conv_x6_kernel(ConvX6Args a)
+{
+    typedef GeoX<KH, KW> G;
+    __shared__ u32x4 lds[2 * G::PIECES];
+    const int tiles_x = a.W >> 4, tiles = tiles_x * (a.H >> 4);
+    const int n = blockIdx.x / tiles, t = blockIdx.x - n * tiles, ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, xl = lane & 15, g = lane >> 4;
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    x6_accumulate<KH, KW, NT>(a.x, a.x_stride, a.w, a.Cin, a.H, a.W, n, ty, tx, lds, acc);
+    if (a.x_sc) x6_accumulate<1, 1, NT>(a.x_sc, a.sc_stride, a.w_sc, a.Csc, a.H, a.W, n, ty, tx, lds, acc);
+
+    const int H = a.H, W = a.W;
+    const size_t grp = (size_t)H * W * 16;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int y = ty * 16 + wave * 4 + m, x = tx * 16 + xl;
+            const size_t off = ((size_t)n * NT + nt) * grp + ((size_t)y * W + x) * 16 + g * 4;
+            f32x4 v = acc[m][nt];
+            if (a.res) v += load_split4(a.res + off, a.res_stride);
+            if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (a.gate) v *= load_split4(a.gate + off, a.gate_stride);
+            acc[m][nt] = v;
+        }
+        if (!a.pool) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int y = ty * 16 + wave * 4 + m, x = tx * 16 + xl;
+                const size_t off = ((size_t)n * NT + nt) * grp + ((size_t)y * W + x) * 16 + g * 4;
+                if (a.out_f32) *reinterpret_cast<f32x4 *>(a.out_f32 + off) = acc[m][nt];
+                else store_split4(a.out + off, a.out_stride, acc[m][nt]);
+            }
+        } else {
+            const int Ho = H >> 1, Wo = W >> 1;
+#pragma unroll
+            for (int m = 0; m < 4; m += 2) {
+                f32x4 v = acc[m][nt], u = acc[m + 1][nt];
+                v.x = fmaxf(v.x, u.x); v.y = fmaxf(v.y, u.y); v.z = fmaxf(v.z, u.z); v.w = fmaxf(v.w, u.w);
+                f32x4 o;
+                o.x = __shfl_xor(v.x, 1); o.y = __shfl_xor(v.y, 1); o.z = __shfl_xor(v.z, 1); o.w = __shfl_xor(v.w, 1);
+                v.x = fmaxf(v.x, o.x); v.y = fmaxf(v.y, o.y); v.z = fmaxf(v.z, o.z); v.w = fmaxf(v.w, o.w);
+                if ((xl & 1) == 0) {
+                    const int yo = ty * 8 + wave * 2 + (m >> 1), xo = tx * 8 + (xl >> 1);
+                    const size_t off = (((size_t)n * NT + nt) * Ho + yo) * Wo * 16 + (size_t)xo * 16 + g * 4;
+                    if (a.out_f32) *reinterpret_cast<f32x4 *>(a.out_f32 + off) = v;
+                    else store_split4(a.out + off, a.out_stride, v);
+                }
+            }
+        }
+    }
+}
+
+template <int KH, int KW>
+static hipError_t launch_x6(hipStream_t s, const ConvX6Args &a)
+{
+    const int grid = a.N * (a.H >> 4) * (a.W >> 4);
+    switch (a.Cout >> 4) {
+    case 1: hipLaunchKernelGGL((conv_x6_kernel<KH, KW, 1>), dim3(grid), dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((conv_x6_kernel<KH, KW, 2>), dim3(grid), dim3(256), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((conv_x6_kernel<KH, KW, 4>), dim3(grid), dim3(256), 0, s, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_x6(hipStream_t s, const ConvX6Args &a)
+{
+    if ((a.H & 15) || (a.W & 15) || (a.Cin & 15) || (a.Cout & 15) || (a.x_sc && (a.Csc & 15)) || a.N <= 0)
+        return hipErrorInvalidValue;
+    if (a.pool && a.gate) return hipErrorInvalidValue;
+    if (a.KH == 3 && a.KW == 3) return launch_x6<3, 3>(s, a);
+    if (a.KH == 5 && a.KW == 5) return launch_x6<5, 5>(s, a);
+    if (a.KH == 1 && a.KW == 1) return launch_x6<1, 1>(s, a);
+    return hipErrorInvalidValue;
+}
+
+// ---- format converters ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void f32_to_split3_kernel(const float *__restrict__ x, unsigned short *__restrict__ out,
+                                                            size_t n4, size_t plane_stride)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
+        store_split4(out + i * 4, plane_stride, *reinterpret_cast<const f32x4 *>(x + i * 4));
+}
+
+__global__ __launch_bounds__(256) void split3_to_f32_kernel(const unsigned short *__restrict__ x, float *__restrict__ out,
+                                                            size_t n4, size_t plane_stride)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
+        *reinterpret_cast<f32x4 *>(out + i * 4) = load_split4(x + i * 4, plane_stride);
+}
+
+hipError_t launch_f32_to_split3(hipStream_t s, const float *x, unsigned short *out, size_t n, size_t plane_stride)
+{
+    const size_t n4 = n / 4;
+    const unsigned grid = (unsigned)((n4 + 255) / 256 > 16384 ? 16384 : (n4 + 255) / 256);
+    if (n4) hipLaunchKernelGGL(f32_to_split3_kernel, dim3(grid), dim3(256), 0, s, x, out, n4, plane_stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_split3_to_f32(hipStream_t s, const unsigned short *x, float *out, size_t n, size_t plane_stride)
+{
+    const size_t n4 = n / 4;
+    const unsigned grid = (unsigned)((n4 + 255) / 256 > 16384 ? 16384 : (n4 + 255) / 256);
+    if (n4) hipLaunchKernelGGL(split3_to_f32_kernel, dim3(grid), dim3(256), 0, s, x, out, n4, plane_stride);
+    return hipGetLastError();
+}
+
+}  // namespace pmp

@@ -1,12 +1,16 @@
 // nets.cpp — the four Down-Up-CNN forward passes (Model_QBD.py:59-253) as sequences of HIP kernel launches.
 //
-// Every activation is a blocked channels-last tensor [n][C/16][H][W][16] carved from the context's workspace
-// arena.  Fusions relative to the reference's op-by-op graph:
+// Every activation is a blocked channels-last tensor [n][C/16][H][W][16] carved from the context's workspace arena,
+// either plain fp32 or "split-3" (three bf16 planes, conv_bf16x6.hip) when the context runs the bf16x6 datapath.
+// Fusions relative to the reference's op-by-op graph:
 //   * conv + ReLU; conv + (identity | 1x1-conv shortcut) + ReLU                 (ResidualBlock.forward :40-44)
 //   * ... + 2x2 max-pool in the same epilogue                                   (:81-82,:89,:136-137,:151)
 //   * ... + attention multiply x5*att / x4*att in the epilogue of the Att trunk (:143,:150)
 //   * ZeroPad2d / interpolate / cat of the stems are index arithmetic inside the stem kernel (:79,:130-135)
 //   * head accumulation out_k[:,0] += out_{k-1}[:,0] inside the head kernel     (:146,:153)
+// In bf16x6 mode tensors that only feed MFMA convs stay split-3; tensors read by the small fp32 kernels (heads,
+// 8x8 tail, multi-scale pool, attention inputs) are written as fp32 by the producing conv, and the three fp32-born
+// inputs of MFMA convs (stem output, x6, attention inputs) pass through a split kernel.
 #include "pmp_host.h"
 
 namespace pmp {
@@ -14,8 +18,12 @@ namespace pmp {
 namespace {
 
 struct Act {
-    float *p;
-    int C, H, W;  // C padded to 16
+    float *p;      // fp32 tensor, or the first of three bf16 planes when split
+    int C, H, W;   // C padded to 16
+    bool split;
+    size_t stride; // elements between split planes
+    const unsigned short *s() const { return reinterpret_cast<const unsigned short *>(p); }
+    unsigned short *s() { return reinterpret_cast<unsigned short *>(p); }
 };
 
 struct Graph {
@@ -23,11 +31,15 @@ struct Graph {
     const NetWeights &w;
     int n;
     int rc = PMP_OK;
+    bool x6() const { return c->precision == 1; }
 
-    Act alloc(int C, int H, int W)
+    Act alloc(int C, int H, int W, bool split)
     {
         const int cp = (C + 15) & ~15;
-        return Act{c->arena.get((size_t)c->chunk * cp * H * W), cp, H, W};
+        const size_t elems = (size_t)c->chunk * cp * H * W;
+        // split-3: 3 planes of 2-byte elements = 1.5 floats per element
+        float *p = c->arena.get(split ? (elems * 3 + 1) / 2 : elems);
+        return Act{p, cp, H, W, split, elems};
     }
 
     bool check(hipError_t e, const char *what)
@@ -35,26 +47,66 @@ struct Graph {
         if (e != hipSuccess && rc == PMP_OK) rc = hip_fail(c, e, what);
         return rc == PMP_OK;
     }
+    bool live() const { return !c->arena.measuring && rc == PMP_OK; }
 
     int kclass(int k, int cin, int cout) const
     {
-        if (cin >= 32 && cout == 64 && k == 3 && cin == 64) return K_CONV3_64;
+        if (cout == 64 && cin == 64 && k == 3) return K_CONV3_64;
         if (cout == 64 && k == 5) return K_CONV5_64;
         return K_CONV_OTHER;
     }
 
-    // ResidualBlock (Model_QBD.py:23-44) with optional fused gate / pool.
-    Act rb(const Act &x, const std::string &name, bool pool = false, const Act *gate = nullptr)
+    // fp32 tensor -> split-3 (no-op in fp32 mode)
+    Act to_conv_input(const Act &x)
+    {
+        if (!x6() || x.split) return x;
+        Act y = alloc(x.C, x.H, x.W, true);
+        if (live()) {
+            KScope ks(c, K_SMALL, 0.0);
+            check(launch_f32_to_split3(c->stream, x.p, y.s(), (size_t)n * x.C * x.H * x.W, y.stride), "f32_to_split3");
+        }
+        return y;
+    }
+
+    // One convolution of a residual block on the MFMA path of the active datapath.
+    void conv(const Act &x, const RBWeights &r, bool second, const Act *sc_src, const Act *res, const Act *gate, bool pool,
+              Act &out, double flops, int cls)
+    {
+        if (!live()) return;
+        KScope ks(c, cls, flops);
+        if (x6()) {
+            ConvX6Args a{};
+            a.x = x.s(); a.x_stride = x.stride; a.w = second ? r.w2x : r.w0x;
+            if (sc_src) { a.x_sc = sc_src->s(); a.sc_stride = sc_src->stride; a.w_sc = r.wscx; a.Csc = sc_src->C; }
+            if (res) { a.res = res->s(); a.res_stride = res->stride; }
+            if (gate) { a.gate = gate->s(); a.gate_stride = gate->stride; }
+            if (out.split) { a.out = out.s(); a.out_stride = out.stride; }
+            else a.out_f32 = out.p;
+            a.N = n; a.H = x.H; a.W = x.W; a.Cin = x.C; a.Cout = out.C; a.KH = a.KW = r.k; a.relu = 1; a.pool = pool ? 1 : 0;
+            check(launch_conv_x6(c->stream, a), "conv_x6");
+        } else {
+            ConvMfmaArgs a{};
+            a.x = x.p; a.w = second ? r.w2 : r.w0; a.out = out.p;
+            if (sc_src) { a.x_sc = sc_src->p; a.w_sc = r.wsc; a.Csc = sc_src->C; }
+            if (res) a.res = res->p;
+            if (gate) a.gate = gate->p;
+            a.N = n; a.H = x.H; a.W = x.W; a.Cin = x.C; a.Cout = out.C; a.KH = a.KW = r.k; a.relu = 1; a.pool = pool ? 1 : 0;
+            check(launch_conv_mfma(c->stream, a), "conv_mfma");
+        }
+    }
+
+    // ResidualBlock (Model_QBD.py:23-44) with optional fused gate / pool.  out_f32: the consumer is not an MFMA conv.
+    Act rb(const Act &x_in, const std::string &name, bool pool = false, const Act *gate = nullptr, bool out_f32 = false)
     {
         auto it = w.rb.find(name);
-        if (it == w.rb.end()) { if (rc == PMP_OK) rc = set_err(c, PMP_E_INVALID, "graph: no weights for " + name); return x; }
+        if (it == w.rb.end()) { if (rc == PMP_OK) rc = set_err(c, PMP_E_INVALID, "graph: no weights for " + name); return x_in; }
         const RBWeights &r = it->second;
-        const int H = x.H, W = x.W;
-        Act t = alloc(r.cout, H, W);
-        Act y = alloc(r.cout, pool ? H / 2 : H, pool ? W / 2 : W);
-        if (c->arena.measuring || rc != PMP_OK) return y;
+        const int H = x_in.H, W = x_in.W;
         const double px = (double)n * H * W;
-        if (r.direct) {
+        if (r.direct) {  // 8x8 maps: plain fp32 kernels in both modes
+            Act t = alloc(r.cout, H, W, false), y = alloc(r.cout, pool ? H / 2 : H, pool ? W / 2 : W, false);
+            if (!live()) return y;
+            const Act &x = x_in;
             ConvDirectArgs a{};
             a.x = x.p; a.w = r.w0; a.out = t.p;
             a.N = n; a.H = H; a.W = W; a.Cin = r.cin; a.CinPad = x.C; a.Cout = r.cout; a.CoutPad = t.C;
@@ -69,26 +121,20 @@ struct Graph {
             { KScope ks(c, K_SMALL, 2.0 * px * r.cout * (r.cout * r.k * r.k + (r.wsc ? r.cin : 0))); check(launch_conv_direct(c->stream, b), "conv_direct"); }
             return y;
         }
-        ConvMfmaArgs a{};
-        a.x = x.p; a.w = r.w0; a.out = t.p;
-        a.N = n; a.H = H; a.W = W; a.Cin = x.C; a.Cout = t.C; a.KH = a.KW = r.k; a.relu = 1;
-        { KScope ks(c, kclass(r.k, r.cin, r.cout), 2.0 * px * r.cout * r.cin * r.k * r.k); check(launch_conv_mfma(c->stream, a), "conv_mfma"); }
-        ConvMfmaArgs b{};
-        b.x = t.p; b.w = r.w2; b.out = y.p;
-        b.N = n; b.H = H; b.W = W; b.Cin = t.C; b.Cout = y.C; b.KH = b.KW = r.k; b.relu = 1;
-        b.pool = pool ? 1 : 0;
-        b.gate = gate ? gate->p : nullptr;
-        if (r.wsc) { b.x_sc = x.p; b.w_sc = r.wsc; b.Csc = x.C; }
-        else b.res = x.p;
-        { KScope ks(c, kclass(r.k, r.cout, r.cout), 2.0 * px * r.cout * (r.cout * r.k * r.k + (r.wsc ? r.cin : 0))); check(launch_conv_mfma(c->stream, b), "conv_mfma"); }
+        const Act x = to_conv_input(x_in);
+        Act t = alloc(r.cout, H, W, x6());
+        Act y = alloc(r.cout, pool ? H / 2 : H, pool ? W / 2 : W, x6() && !out_f32);
+        conv(x, r, false, nullptr, nullptr, nullptr, false, t, 2.0 * px * r.cout * r.cin * r.k * r.k, kclass(r.k, r.cin, r.cout));
+        conv(t, r, true, r.wsc ? &x : nullptr, r.wsc ? nullptr : &x, gate, pool, y,
+             2.0 * px * r.cout * (r.cout * r.k * r.k + (r.wsc ? r.cin : 0)), kclass(r.k, r.cout, r.cout));
         return y;
     }
 
     Act stem(bool luma, bool msbd, const uint8_t *by, const uint8_t *bu, const uint8_t *bv, const float *q)
     {
         const int S = luma ? 64 : 32;
-        Act o = alloc(32, S, S);
-        if (c->arena.measuring || rc != PMP_OK) return o;
+        Act o = alloc(32, S, S, false);
+        if (!live()) return o;
         StemArgs a{by, bu, bv, q, w.stem_w, w.stem_b, o.p, n};
         const int cin = (luma ? 1 : 3) + (msbd ? 1 : 0), k1 = luma ? 9 : 5, k2 = luma ? 5 : 3;
         const double macs = msbd ? (double)cin * (k1 * k1 * 16 + 2 * k1 * k2 * 8) : (double)cin * k1 * k1 * 32;
@@ -99,7 +145,7 @@ struct Graph {
 
     void head(const Act &x, int slot, int layer, float *qt, float *bt, float *dire)
     {
-        if (c->arena.measuring || rc != PMP_OK) return;
+        if (!live()) return;
         HeadArgs a{x.p, w.head_w[slot], w.head_b[slot], qt, bt, dire, n, x.H, layer};
         KScope ks(c, K_SMALL, 2.0 * n * x.H * x.W * 72.0 * (layer < 0 ? 1 : 2));
         check(launch_head(c->stream, a), "head");
@@ -116,14 +162,14 @@ int forward_q(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, con
     Act x2 = g.stem(luma, false, by, bu, bv, nullptr);
     Act x3 = g.rb(x2, "resblock_q1", luma);            // luma: + max_pool2d(2); chroma: no pool (:179)
     Act x4 = g.rb(x3, "resblock_q2", true);
-    Act x5 = g.rb(x4, "resblock_q3");
-    Act x6 = g.alloc(128, 16, 16);
-    if (!c->arena.measuring && g.rc == PMP_OK) {
+    Act x5 = g.rb(x4, "resblock_q3", false, nullptr, true);   // fp32: read by the multi-scale pool kernel
+    Act x6 = g.alloc(128, 16, 16, false);
+    if (g.live()) {
         KScope ks(c, K_SMALL, 0.0);
         g.check(launch_multipool_concat(c->stream, x5.p, x6.p, n), "multipool_concat");
     }
     Act x7 = g.rb(x6, "resblock_q4");
-    Act x8 = g.rb(x7, "resblock_q5", true);
+    Act x8 = g.rb(x7, "resblock_q5", true, nullptr, true);    // fp32: 8x8 tail runs on the direct kernel
     Act x9 = g.rb(x8, "resblock_q6");
     g.head(x9, 0, -1, qt, nullptr, nullptr);
     return g.rc;
@@ -142,25 +188,25 @@ int forward_msbd(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, 
     for (int i = 0; i < 3; ++i) x = g.rb(x, "trunk_M2." + std::to_string(i));
     Act x5 = g.rb(x, "trunk_M2.3", true);
     // branch B1 -> out0
-    Act b = g.rb(g.rb(g.rb(x5, "trunk_B1.0"), "trunk_B1.1"), "trunk_B1.2");
+    Act b = g.rb(g.rb(g.rb(x5, "trunk_B1.0"), "trunk_B1.1"), "trunk_B1.2", false, nullptr, true);
     g.head(b, 0, 0, nullptr, bt, dire);
     // attention 1 gates x5 (:140-143), branch B2 -> out1 (accumulated in the head kernel, :146)
-    Act ai = g.alloc(16, 16, 16);
-    if (!c->arena.measuring && g.rc == PMP_OK) {
+    Act ai = g.alloc(16, 16, 16, false);
+    if (g.live()) {
         KScope ks(c, K_SMALL, 0.0);
         g.check(launch_att_input(c->stream, qt, bt, dire, 0, ai.p, n, 16), "att_input");
     }
     Act xb1 = g.rb(g.rb(ai, "trunk_Att1.0"), "trunk_Att1.1", false, &x5);
-    b = g.rb(g.rb(g.rb(xb1, "trunk_B2.0"), "trunk_B2.1"), "trunk_B2.2");
+    b = g.rb(g.rb(g.rb(xb1, "trunk_B2.0"), "trunk_B2.1"), "trunk_B2.2", false, nullptr, true);
     g.head(b, 1, 1, nullptr, bt, dire);
     // attention 2 gates x4 at 32x32 (:147-150), branch B3 -> pool -> out2 (:151-153)
-    Act aj = g.alloc(16, 32, 32);
-    if (!c->arena.measuring && g.rc == PMP_OK) {
+    Act aj = g.alloc(16, 32, 32, false);
+    if (g.live()) {
         KScope ks(c, K_SMALL, 0.0);
         g.check(launch_att_input(c->stream, qt, bt, dire, 1, aj.p, n, 32), "att_input");
     }
     Act xb3 = g.rb(g.rb(aj, "trunk_Att2.0"), "trunk_Att2.1", false, &x4);
-    b = g.rb(g.rb(g.rb(xb3, "trunk_B3.0"), "trunk_B3.1"), "trunk_B3.2", true);
+    b = g.rb(g.rb(g.rb(xb3, "trunk_B3.0"), "trunk_B3.1"), "trunk_B3.2", true, nullptr, true);
     g.head(b, 2, 2, nullptr, bt, dire);
     return g.rc;
 }

@@ -1,7 +1,9 @@
 // pmp_api.cpp — the C ABI declared in include/pmp.h.
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "pmp_host.h"
 
@@ -151,7 +153,7 @@ using namespace pmp;
 
 extern "C" {
 
-const char *pmp_version(void) { return "pmp-hip 0.1 (gfx950, fp32 MFMA)"; }
+const char *pmp_version(void) { return "pmp-hip 0.2 (gfx950; fp32 MFMA + bf16x6 split MFMA)"; }
 
 const char *pmp_last_error(const pmp_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 
@@ -210,6 +212,18 @@ int pmp_set_chunk(pmp_ctx *c, int blocks)
     c->chunk = blocks;
     return PMP_OK;
 }
+
+int pmp_set_precision(pmp_ctx *c, int mode)
+{
+    CHECK_CTX(c);
+    if (mode != PMP_PRECISION_F32 && mode != PMP_PRECISION_BF16X6) return set_err(c, PMP_E_INVALID, "pmp_set_precision: 0 (fp32) or 1 (bf16x6)");
+    int rc = sync(c);
+    if (rc != PMP_OK) return rc;
+    c->precision = mode;
+    return PMP_OK;
+}
+
+int pmp_get_precision(const pmp_ctx *c) { return c ? c->precision : PMP_E_INVALID; }
 
 int pmp_load_weights(pmp_ctx *c, int net_id, int qp, const float *blob, const pmp_tensor_desc *descs, int ndesc)
 {
@@ -438,6 +452,70 @@ int pmp_debug_set_conv_variant(int variant)
     if (variant < 0 || variant > 2) return set_err(nullptr, PMP_E_INVALID, "pmp_debug_set_conv_variant: 0..2");
     g_conv_variant = variant;
     return PMP_OK;
+}
+
+int pmp_debug_conv_bench(pmp_ctx *c, int n, int h, int w, int cin, int cout, int k, int iters, double *ms_f32, double *ms_x6,
+                         double *max_abs_diff, double *max_abs_ref)
+{
+    CHECK_CTX(c);
+    if (n <= 0 || (h & 15) || (w & 15) || (cin & 15) || (cout & 15) || cout > 64 || (k != 1 && k != 3 && k != 5) || iters <= 0)
+        return set_err(c, PMP_E_INVALID, "pmp_debug_conv_bench: bad shape");
+    const size_t nx = (size_t)n * cin * h * w, ny = (size_t)n * cout * h * w;
+    std::vector<float> hx(nx), hw((size_t)cout * cin * k * k);
+    unsigned long long st = 0x1234567ull;
+    auto rnd = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (float)((st >> 40) / 16777216.0) * 2.f - 1.f; };
+    for (auto &v : hx) v = rnd() * 3.f;
+    const float ws = 1.f / sqrtf((float)cin * k * k);
+    for (auto &v : hw) v = rnd() * ws;
+    std::vector<float> wp = pack_mfma(hw.data(), cout, cin, k, k, cout, cin);
+    std::vector<unsigned short> wx = pack_x6(hw.data(), cout, cin, k, k, cout, cin);
+    float *dx = nullptr, *dy = nullptr, *dy2 = nullptr, *dwp = nullptr;
+    unsigned short *dxs = nullptr, *dys = nullptr, *dwx = nullptr;
+    hipError_t e = hipSuccess;
+    auto A = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
+    A((void **)&dx, nx * 4); A((void **)&dy, ny * 4); A((void **)&dy2, ny * 4); A((void **)&dwp, wp.size() * 4);
+    A((void **)&dxs, nx * 6); A((void **)&dys, ny * 6); A((void **)&dwx, wx.size() * 2);
+    int rc = PMP_OK;
+    if (e != hipSuccess) rc = hip_fail(c, e, "hipMalloc(conv bench)");
+    if (rc == PMP_OK) {
+        hipMemcpy(dx, hx.data(), nx * 4, hipMemcpyHostToDevice);
+        hipMemcpy(dwp, wp.data(), wp.size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(dwx, wx.data(), wx.size() * 2, hipMemcpyHostToDevice);
+        ConvMfmaArgs a{};
+        a.x = dx; a.w = dwp; a.out = dy; a.N = n; a.H = h; a.W = w; a.Cin = cin; a.Cout = cout; a.KH = a.KW = k; a.relu = 1;
+        ConvX6Args b{};
+        b.x = dxs; b.x_stride = nx; b.w = dwx; b.out = dys; b.out_stride = ny;
+        b.N = n; b.H = h; b.W = w; b.Cin = cin; b.Cout = cout; b.KH = b.KW = k; b.relu = 1;
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        launch_f32_to_split3(c->stream, dx, dxs, nx, nx);
+        launch_conv_mfma(c->stream, a);
+        e = launch_conv_x6(c->stream, b);
+        float ms = 0.f;
+        hipEventRecord(e0, c->stream);
+        for (int i = 0; i < iters; ++i) launch_conv_mfma(c->stream, a);
+        hipEventRecord(e1, c->stream); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+        if (ms_f32) *ms_f32 = ms / iters;
+        hipEventRecord(e0, c->stream);
+        for (int i = 0; i < iters; ++i) launch_conv_x6(c->stream, b);
+        hipEventRecord(e1, c->stream); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+        if (ms_x6) *ms_x6 = ms / iters;
+        launch_split3_to_f32(c->stream, dys, dy2, ny, ny);
+        std::vector<float> y1(ny), y2(ny);
+        hipMemcpyAsync(y1.data(), dy, ny * 4, hipMemcpyDeviceToHost, c->stream);
+        hipMemcpyAsync(y2.data(), dy2, ny * 4, hipMemcpyDeviceToHost, c->stream);
+        hipError_t es = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = es;
+        if (e == hipSuccess) e = hipGetLastError();
+        double md = 0, mr = 0;
+        for (size_t i = 0; i < ny; ++i) { md = fmax(md, fabs((double)y1[i] - y2[i])); mr = fmax(mr, fabs((double)y1[i])); }
+        if (max_abs_diff) *max_abs_diff = md;
+        if (max_abs_ref) *max_abs_ref = mr;
+        hipEventDestroy(e0); hipEventDestroy(e1);
+        if (e != hipSuccess) rc = hip_fail(c, e, "conv bench");
+    }
+    for (void *p : {(void *)dx, (void *)dy, (void *)dy2, (void *)dwp, (void *)dxs, (void *)dys, (void *)dwx}) if (p) hipFree(p);
+    return rc;
 }
 
 // ---- timing ------------------------------------------------------------------------------------------------

@@ -23,7 +23,8 @@ struct DevBuf {  // grow-only device buffer
 struct RBWeights {
     int cin = 0, cout = 0, k = 0;      // real dims
     int cin_pad = 0, cout_pad = 0;
-    float *w0 = nullptr, *w2 = nullptr, *wsc = nullptr;  // MFMA packing (or direct packing when `direct`)
+    float *w0 = nullptr, *w2 = nullptr, *wsc = nullptr;  // fp32 MFMA packing (or direct packing when `direct`)
+    unsigned short *w0x = nullptr, *w2x = nullptr, *wscx = nullptr;  // bf16x6 split packing (conv_bf16x6.hip)
     bool direct = false;               // 8x8 layers run on the direct kernel
 };
 
@@ -57,6 +58,7 @@ struct pmp_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     int chunk = 1024;
+    int precision = 1;                     // 0: fp32 MFMA, 1: bf16x6 split (fp32-equivalent, default)
     std::string err;
     std::map<int, pmp::NetWeights> nets;  // key = net_id * 100 + qp
     pmp::Arena arena;
@@ -78,6 +80,8 @@ int hip_fail(pmp_ctx *c, hipError_t e, const char *what);
 // weights_pack.cpp
 int load_net_weights(pmp_ctx *c, int net_id, int qp, const float *blob, const pmp_tensor_desc *descs, int ndesc);
 void free_net_weights(NetWeights &w);
+std::vector<float> pack_mfma(const float *w, int cout, int cin, int kh, int kw, int cout_pad, int cin_pad);
+std::vector<unsigned short> pack_x6(const float *w, int cout, int cin, int kh, int kw, int cout_pad, int cin_pad);
 
 // nets.cpp: forward graphs on device pointers (n <= chunk); all launches go to c->stream.
 int forward_q(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, const uint8_t *bu, const uint8_t *bv,

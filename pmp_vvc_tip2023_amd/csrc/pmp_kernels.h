@@ -27,6 +27,25 @@ struct ConvMfmaArgs {
 hipError_t launch_conv_mfma(hipStream_t s, const ConvMfmaArgs &a);
 extern int g_conv_variant;  // see pmp_debug_set_conv_variant
 
+// ------------------------------------------------------------------------------------------------ conv (bf16 x 6)
+// Same operation on "split-3" activations (three bf16 planes per tensor, conv_bf16x6.hip).  *_stride = elements between
+// the planes of the respective tensor.  Output goes to split-3 planes (`out`) or, if out_f32 != nullptr, to a plain
+// fp32 blocked tensor (for consumers that are not MFMA convs).
+struct ConvX6Args {
+    const unsigned short *x; size_t x_stride;
+    const unsigned short *w;                 // packed [Cin/16][ceil(taps/2)][3 splits][Cout/16][64 lanes][8 bf16]
+    const unsigned short *x_sc; size_t sc_stride; const unsigned short *w_sc;
+    const unsigned short *res; size_t res_stride;
+    const unsigned short *gate; size_t gate_stride;
+    unsigned short *out; size_t out_stride;
+    float *out_f32;
+    int N, H, W, Cin, Csc, Cout, KH, KW;
+    int relu, pool;
+};
+hipError_t launch_conv_x6(hipStream_t s, const ConvX6Args &a);
+hipError_t launch_f32_to_split3(hipStream_t s, const float *x, unsigned short *out, size_t n, size_t plane_stride);
+hipError_t launch_split3_to_f32(hipStream_t s, const unsigned short *x, float *out, size_t n, size_t plane_stride);
+
 // ------------------------------------------------------------------------------------------------ stems
 // First layers straight from the u8 blocks (Model_QBD.py:79-80, :130-135, :177-178, :228-233).
 // luma: block_y u8[N][68][68];  chroma: + block_u/v u8[N][34][34], plane 0 = 2x2 max-pool of block_y

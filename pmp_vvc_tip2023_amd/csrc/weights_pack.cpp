@@ -39,10 +39,22 @@ struct Uploader {
         *out = static_cast<float *>(d);
         return PMP_OK;
     }
+    int upload16(const std::vector<unsigned short> &h, unsigned short **out)
+    {
+        void *d = nullptr;
+        hipError_t e = hipMalloc(&d, h.size() * sizeof(unsigned short));
+        if (e != hipSuccess) return hip_fail(c, e, "hipMalloc(weights)");
+        e = hipMemcpy(d, h.data(), h.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { hipFree(d); return hip_fail(c, e, "hipMemcpy(weights)"); }
+        nw->allocs.push_back(d);
+        *out = static_cast<unsigned short *>(d);
+        return PMP_OK;
+    }
 };
 
 // OIHW conv weight -> MFMA A-operand fragments [Cin_pad/16][KH*KW][Cout_pad/16][64 lanes][4]:
 // lane l of cout-tile nt holds W[cout = 16nt + (l&15)][channel = 16cb + 4(l>>4) + j], j = 0..3 (conv_mfma.hip).
+}  // namespace
 std::vector<float> pack_mfma(const float *w, int cout, int cin, int kh, int kw, int cout_pad, int cin_pad)
 {
     const int taps = kh * kw, CB = cin_pad / 16, NT = cout_pad / 16;
@@ -59,6 +71,54 @@ std::vector<float> pack_mfma(const float *w, int cout, int cin, int kh, int kw, 
                     }
     return out;
 }
+namespace {
+
+}  // namespace
+
+// fp32 -> bf16, round to nearest even (weights are finite)
+static inline unsigned short bf16_rne(float f)
+{
+    unsigned u;
+    std::memcpy(&u, &f, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+static inline float bf16_f32(unsigned short h)
+{
+    unsigned u = (unsigned)h << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+// OIHW conv weight -> split-3 bf16 MFMA A-operand fragments (conv_bf16x6.hip):
+// [Cin_pad/16][ceil(taps/2)][3 splits][Cout_pad/16][64 lanes][8]; lane l of cout-tile nt holds
+// W[cout = 16nt + (l&15)][channel = 16cb + 8((l>>4)&1) + j][tap = 2ks + (l>>5)], zero beyond the last tap.
+std::vector<unsigned short> pack_x6(const float *w, int cout, int cin, int kh, int kw, int cout_pad, int cin_pad)
+{
+    const int taps = kh * kw, nks = (taps + 1) / 2, CB = cin_pad / 16, NT = cout_pad / 16;
+    std::vector<unsigned short> out((size_t)CB * nks * 3 * NT * 64 * 8, 0);
+    for (int cb = 0; cb < CB; ++cb)
+        for (int ks = 0; ks < nks; ++ks)
+            for (int nt = 0; nt < NT; ++nt)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 8; ++j) {
+                        const int co = nt * 16 + (l & 15), g = l >> 4, ci = cb * 16 + 8 * (g & 1) + j, t = 2 * ks + (g >> 1);
+                        float v = 0.f;
+                        if (co < cout && ci < cin && t < taps) v = w[((size_t)co * cin + ci) * taps + t];
+                        const unsigned short h0 = bf16_rne(v);
+                        const float r1 = v - bf16_f32(h0);
+                        const unsigned short h1 = bf16_rne(r1);
+                        const float r2 = r1 - bf16_f32(h1);
+                        const unsigned short h2 = bf16_rne(r2);
+                        const unsigned short hs[3] = {h0, h1, h2};
+                        for (int sp = 0; sp < 3; ++sp)
+                            out[(((((size_t)cb * nks + ks) * 3 + sp) * NT + nt) * 64 + l) * 8 + j] = hs[sp];
+                    }
+    return out;
+}
+
+namespace {
 
 // OIHW -> [tap][cin][cout] (direct kernels, stems, heads)
 std::vector<float> pack_plain(const float *w, int cout, int cin, int kh, int kw)
@@ -101,6 +161,9 @@ int load_rb(pmp_ctx *c, const Blob &b, Uploader &up, const std::string &name, in
         if ((rc = up.upload(pack_mfma(w0, cout, cin, k, k, r.cout_pad, r.cin_pad), &r.w0))) return rc;
         if ((rc = up.upload(pack_mfma(w2, cout, cout, k, k, r.cout_pad, r.cout_pad), &r.w2))) return rc;
         if (wsc && (rc = up.upload(pack_mfma(wsc, cout, cin, 1, 1, r.cout_pad, r.cin_pad), &r.wsc))) return rc;
+        if ((rc = up.upload16(pack_x6(w0, cout, cin, k, k, r.cout_pad, r.cin_pad), &r.w0x))) return rc;
+        if ((rc = up.upload16(pack_x6(w2, cout, cout, k, k, r.cout_pad, r.cout_pad), &r.w2x))) return rc;
+        if (wsc && (rc = up.upload16(pack_x6(wsc, cout, cin, 1, 1, r.cout_pad, r.cin_pad), &r.wscx))) return rc;
     }
     up.nw->rb[name] = r;
     return PMP_OK;

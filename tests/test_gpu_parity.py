@@ -10,10 +10,13 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3  # north_star: "within 1e-3 fp32 on the map logits"
 
 
-@pytest.fixture(scope="module")
-def eng():
+@pytest.fixture(scope="module", params=["bf16x6", "fp32"])
+def eng(request):
+    """Every parity test runs on both convolution datapaths (default bf16x6 split and exact fp32 MFMA)."""
     from pmp_vvc_tip2023_amd import engine
     e = engine.Engine(0)
+    e.set_precision(request.param)
+    assert e.get_precision() == request.param
     yield e
     e.close()
 
