@@ -41,41 +41,59 @@ struct GeoX {
     static constexpr int NLD = (PIECES + 255) / 256;
 };
 
-// global -> registers: unconditional loads (clamped coordinates) so hipcc can count them (see conv_mfma.hip)
+// Per-lane staging plan, computed ONCE per workgroup: element offset (inside one 16-channel group, split plane
+// included) of each 16-B piece this thread copies, and a validity mask for the zero padding.  The per-group work is then
+// one add per piece; recomputing the div/mod chain per group cost ~80 VALU issue slots per K-step, which matters when a
+// 16-cycle bf16 MFMA leaves only 8 free issue cycles.
 template <int KH, int KW>
-__device__ __forceinline__ void x6_stage_load(const unsigned short *__restrict__ grp, size_t plane_stride, int H, int W,
-                                              int ty, int tx, u32x4 (&r)[GeoX<KH, KW>::NLD])
+struct StagePlan {
+    unsigned off[GeoX<KH, KW>::NLD];
+    unsigned valid;
+};
+
+template <int KH, int KW>
+__device__ __forceinline__ void x6_plan(StagePlan<KH, KW> &p, size_t plane_stride, int H, int W, int ty, int tx)
 {
     typedef GeoX<KH, KW> G;
     constexpr int PY = KH / 2, PX = KW / 2;
+    p.valid = 0;
 #pragma unroll
     for (int k = 0; k < G::NLD; ++k) {
         const int i = min((int)threadIdx.x + k * 256, G::PIECES - 1);
         const int sp = i / G::PLANE, j = i - sp * G::PLANE, pix = j >> 1, half = j & 1;
         const int row = pix / G::TW, col = pix - row * G::TW;
-        const int gy = min(max(ty * 16 + row - PY, 0), H - 1), gx = min(max(tx * 16 + col - PX, 0), W - 1);
-        r[k] = *reinterpret_cast<const u32x4 *>(grp + sp * plane_stride + ((size_t)gy * W + gx) * 16 + half * 8);
+        const int gy = ty * 16 + row - PY, gx = tx * 16 + col - PX;
+        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W && (int)threadIdx.x + k * 256 < G::PIECES;
+        if (in) p.valid |= 1u << k;
+        const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);   // clamped: loads stay unconditional
+        p.off[k] = (unsigned)(sp * plane_stride + ((size_t)cy * W + cx) * 16 + half * 8);
     }
 }
 
 template <int KH, int KW>
-__device__ __forceinline__ void x6_stage_store(u32x4 *lds, const u32x4 (&r)[GeoX<KH, KW>::NLD], int H, int W, int ty, int tx)
+__device__ __forceinline__ void x6_stage_load(const StagePlan<KH, KW> &p, const unsigned short *__restrict__ grp,
+                                              u32x4 (&r)[GeoX<KH, KW>::NLD], int k0 = 0, int k1 = 1 << 20)
 {
-    typedef GeoX<KH, KW> G;
-    constexpr int PY = KH / 2, PX = KW / 2;
 #pragma unroll
-    for (int k = 0; k < G::NLD; ++k) {
-        const int i = threadIdx.x + k * 256;
-        const int sp = i / G::PLANE, j = i - sp * G::PLANE, pix = j >> 1;
-        const int row = pix / G::TW, col = pix - row * G::TW;
-        const int gy = ty * 16 + row - PY, gx = tx * 16 + col - PX;
-        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        if (i < G::PIECES) lds[i] = in ? r[k] : z;   // LDS image: [split][pixel][2 halves] 16-B pieces, linear
+    for (int k = 0; k < GeoX<KH, KW>::NLD; ++k) {
+        if (k < k0 || k >= k1) continue;   // folds away: callers pass constants into unrolled code
+        r[k] = *reinterpret_cast<const u32x4 *>(grp + p.off[k]);
     }
 }
 
-template <int KH, int KW, int NT>
+template <int KH, int KW>
+__device__ __forceinline__ void x6_stage_store(const StagePlan<KH, KW> &p, u32x4 *lds, const u32x4 (&r)[GeoX<KH, KW>::NLD])
+{
+    typedef GeoX<KH, KW> G;
+#pragma unroll
+    for (int k = 0; k < G::NLD; ++k) {
+        const int i = threadIdx.x + k * 256;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        if (i < G::PIECES) lds[i] = ((p.valid >> k) & 1u) ? r[k] : z;   // LDS image: [split][pixel][2 halves], linear
+    }
+}
+
+template <int KH, int KW, int NT, int ABL = 0>
 __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__ x, size_t plane_stride,
                                               const unsigned short *__restrict__ wpk, int C, int H, int W, int n, int ty,
                                               int tx, u32x4 *lds, f32x4 (&acc)[4][NT])
@@ -86,63 +104,100 @@ __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__
     const size_t grp_sz = (size_t)H * W * 16;
     const unsigned short *grp0 = x + (size_t)n * CB * grp_sz;
     u32x4 r[G::NLD];
+    StagePlan<KH, KW> plan;
+    x6_plan<KH, KW>(plan, plane_stride, H, W, ty, tx);
     __syncthreads();
-    x6_stage_load<KH, KW>(grp0, plane_stride, H, W, ty, tx, r);
-    x6_stage_store<KH, KW>(lds, r, H, W, ty, tx);
+    x6_stage_load<KH, KW>(plan, grp0, r);
+    x6_stage_store<KH, KW>(plan, lds, r);
     __syncthreads();
-    // weights: [cb][ks][split][nt][lane] 16-B fragments
+    // ---- K-step schedule -------------------------------------------------------------------------------------
+    // Weight fragments live in ONE register set that is refilled in place, split by split, as soon as its last MFMA
+    // of the K-step has been issued: w2 is used once (with x0), w1 twice, w0 three times, so the products are ordered
+    //   phase A: x0*w2            -> request next K-step's w2
+    //   phase B: x0*w1, x1*w1     -> request next w1 and the next K-step's x0 fragments (second register set)
+    //   phase C: x0*w0, x1*w0, x2*w0 -> request next w0
+    // Every request has at least one full phase (256..768 MFMA cycles) before its first use.  All loads are
+    // unconditional so hipcc's s_waitcnt vmcnt(N) are exact counts; scheduling fences pin the phase order.
     const bf16x8 *wl = reinterpret_cast<const bf16x8 *>(wpk) + lane;
+    const int last = CB * G::NKS - 1;
+    bf16x8 w0[NT], w1[NT], w2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { w2[nt] = wl[(2 * NT + nt) * 64]; w1[nt] = wl[(1 * NT + nt) * 64]; w0[nt] = wl[(0 * NT + nt) * 64]; }
+    const int pb = ((wave * 4 * G::TW + xl) * 2 + (g & 1)) * 16;   // bytes inside a split plane, tap (0,0)
+    constexpr int PER = (G::NLD + G::NKS - 1) / G::NKS;            // staging loads issued per K-step
     for (int cb = 0; cb < CB; ++cb) {
         const bool more = cb + 1 < CB;
-        if (more) x6_stage_load<KH, KW>(grp0 + (size_t)(cb + 1) * grp_sz, plane_stride, H, W, ty, tx, r);
+        const unsigned short *nxt_grp = ((ABL & 32) ? x : grp0) + (size_t)min(cb + 1, CB - 1) * grp_sz;   // clamped: loads stay unconditional
         const char *buf = reinterpret_cast<const char *>(lds + (cb & 1) * G::PIECES);
+        bf16x8 xa[4], xb[4], x1[4], x2[4];   // x0 fragments alternate between xa (even K-steps) and xb (odd)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) xa[m] = *reinterpret_cast<const bf16x8 *>(buf + pb + ((g >> 1) ? ((1 / KW) * G::TW + 1 % KW) * 32 * (G::TAPS > 1) : 0) + m * G::TW * 32);
 #pragma unroll
         for (int ks = 0; ks < G::NKS; ++ks) {
-            // this lane's tap of the pair
-            constexpr int dummy = 0; (void)dummy;
             const int t0 = 2 * ks, t1 = (2 * ks + 1 < G::TAPS) ? 2 * ks + 1 : 2 * ks;
-            const int dy0 = t0 / KW, dx0 = t0 % KW, dy1 = t1 / KW, dx1 = t1 % KW;
-            const int dy = (g >> 1) ? dy1 : dy0, dx = (g >> 1) ? dx1 : dx0;
-            const int pbase = (((wave * 4 + dy) * G::TW + xl + dx) * 2 + (g & 1)) * 16;   // bytes inside a split plane
-            const bf16x8 *wk = wl + ((size_t)(cb * G::NKS + ks) * 3 * NT) * 64;
-            bf16x8 wf[3][NT];
+            const int o0 = ((t0 / KW) * G::TW + t0 % KW) * 32, o1 = ((t1 / KW) * G::TW + t1 % KW) * 32;
+            const char *px = buf + pb + ((g >> 1) ? o1 : o0);
+            const int nxt = min(cb * G::NKS + ks + 1, last);
+            const bf16x8 *wk = wl + (size_t)nxt * (3 * NT * 64);
+            bf16x8 (&x0)[4] = (ks & 1) ? xb : xa;
+            bf16x8 (&x0n)[4] = (ks & 1) ? xa : xb;
+            if (!(ABL & 4) || ks == 0) {
 #pragma unroll
-            for (int s = 0; s < 3; ++s)
+                for (int m = 0; m < 4; ++m) x1[m] = *reinterpret_cast<const bf16x8 *>(px + G::PLANE * 16 + m * G::TW * 32);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) wf[s][nt] = wk[(s * NT + nt) * 64];
-            bf16x8 xf[4];
-            // x0 with w0, w1, w2
+                for (int m = 0; m < 4; ++m) x2[m] = *reinterpret_cast<const bf16x8 *>(px + 2 * G::PLANE * 16 + m * G::TW * 32);
+            }
+            if (!(ABL & 1)) x6_stage_load<KH, KW>(plan, nxt_grp, r, ks * PER, (ks + 1) * PER);
+            __builtin_amdgcn_sched_barrier(0);
+            // phase A
 #pragma unroll
-            for (int m = 0; m < 4; ++m) xf[m] = *reinterpret_cast<const bf16x8 *>(buf + pbase + m * G::TW * 32);
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[nt], x0[m], acc[m][nt], 0, 0, 0);
+            if (!(ABL & 2)) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) w2[nt] = wk[(2 * NT + nt) * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // phase B
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2][nt], xf[m], acc[m][nt], 0, 0, 0);
-                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][nt], xf[m], acc[m][nt], 0, 0, 0);
-                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][nt], xf[m], acc[m][nt], 0, 0, 0);
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[nt], x0[m], acc[m][nt], 0, 0, 0);
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[nt], x1[m], acc[m][nt], 0, 0, 0);
                 }
-            // x1 with w0, w1
+            if (!(ABL & 2)) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) xf[m] = *reinterpret_cast<const bf16x8 *>(buf + G::PLANE * 16 + pbase + m * G::TW * 32);
+                for (int nt = 0; nt < NT; ++nt) w1[nt] = wk[(1 * NT + nt) * 64];
+            }
+            if (ks + 1 < G::NKS && !(ABL & 4)) {
+                const int u0 = 2 * ks + 2, u1 = (2 * ks + 3 < G::TAPS) ? 2 * ks + 3 : 2 * ks + 2;
+                const int q0 = ((u0 / KW) * G::TW + u0 % KW) * 32, q1 = ((u1 / KW) * G::TW + u1 % KW) * 32;
+                const char *pn = buf + pb + ((g >> 1) ? q1 : q0);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) x0n[m] = *reinterpret_cast<const bf16x8 *>(pn + m * G::TW * 32);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // phase C
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][nt], xf[m], acc[m][nt], 0, 0, 0);
-                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][nt], xf[m], acc[m][nt], 0, 0, 0);
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[nt], x0[m], acc[m][nt], 0, 0, 0);
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[nt], x1[m], acc[m][nt], 0, 0, 0);
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[nt], x2[m], acc[m][nt], 0, 0, 0);
                 }
-            // x2 with w0
+            if (!(ABL & 2)) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) xf[m] = *reinterpret_cast<const bf16x8 *>(buf + 2 * G::PLANE * 16 + pbase + m * G::TW * 32);
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][nt], xf[m], acc[m][nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) w0[nt] = wk[(0 * NT + nt) * 64];
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) x6_stage_store<KH, KW>(lds + ((cb + 1) & 1) * G::PIECES, r, H, W, ty, tx);
+        // NKS is odd for every kernel size used (1, 5, 13): the last K-step read x0 from xa, as the next group's first will
+        static_assert(G::NKS % 2 == 1, "x0 register alternation assumes an odd number of K-steps per channel group");
+        if (more && !(ABL & 1)) x6_stage_store<KH, KW>(plan, lds + ((cb + 1) & 1) * G::PIECES, r);
+        if (!(ABL & 16))
         __syncthreads();
     }
 }
@@ -168,7 +223,7 @@ __device__ __forceinline__ void store_split4(unsigned short *p, size_t plane_str
     *reinterpret_cast<bf16x4 *>(p + 2 * plane_stride) = c;
 }
 
-template <int KH, int KW, int NT>
+template <int KH, int KW, int NT, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_x6_kernel(ConvX6Args a)
 {
     typedef GeoX<KH, KW> G;
@@ -183,11 +238,20 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(ConvX6Args a)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    x6_accumulate<KH, KW, NT>(a.x, a.x_stride, a.w, a.Cin, a.H, a.W, n, ty, tx, lds, acc);
+    x6_accumulate<KH, KW, NT, ABL>(a.x, a.x_stride, a.w, a.Cin, a.H, a.W, n, ty, tx, lds, acc);
     if (a.x_sc) x6_accumulate<1, 1, NT>(a.x_sc, a.sc_stride, a.w_sc, a.Csc, a.H, a.W, n, ty, tx, lds, acc);
 
     const int H = a.H, W = a.W;
     const size_t grp = (size_t)H * W * 16;
+    if (ABL & 8) {  // timing-only build: skip the epilogue but keep the accumulators live
+        float sacc = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) sacc += acc[m][nt].x + acc[m][nt].y + acc[m][nt].z + acc[m][nt].w;
+        if (sacc == 123.456f) a.out[0] = 1;
+        return;
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -235,7 +299,23 @@ static hipError_t launch_x6(hipStream_t s, const ConvX6Args &a)
     switch (a.Cout >> 4) {
     case 1: hipLaunchKernelGGL((conv_x6_kernel<KH, KW, 1>), dim3(grid), dim3(256), 0, s, a); break;
     case 2: hipLaunchKernelGGL((conv_x6_kernel<KH, KW, 2>), dim3(grid), dim3(256), 0, s, a); break;
-    case 4: hipLaunchKernelGGL((conv_x6_kernel<KH, KW, 4>), dim3(grid), dim3(256), 0, s, a); break;
+    case 4:
+        if (KH == 3 && g_conv_variant >= 10) {  // timing-only ablation builds (tools/conv_x6_bench.py)
+            switch (g_conv_variant - 10) {
+            case 1: hipLaunchKernelGGL((conv_x6_kernel<3, 3, 4, 1>), dim3(grid), dim3(256), 0, s, a); break;
+            case 2: hipLaunchKernelGGL((conv_x6_kernel<3, 3, 4, 2>), dim3(grid), dim3(256), 0, s, a); break;
+            case 4: hipLaunchKernelGGL((conv_x6_kernel<3, 3, 4, 4>), dim3(grid), dim3(256), 0, s, a); break;
+            case 8: hipLaunchKernelGGL((conv_x6_kernel<3, 3, 4, 8>), dim3(grid), dim3(256), 0, s, a); break;
+            case 15: hipLaunchKernelGGL((conv_x6_kernel<3, 3, 4, 15>), dim3(grid), dim3(256), 0, s, a); break;
+            case 16: hipLaunchKernelGGL((conv_x6_kernel<3, 3, 4, 16>), dim3(grid), dim3(256), 0, s, a); break;
+            case 31: hipLaunchKernelGGL((conv_x6_kernel<3, 3, 4, 31>), dim3(grid), dim3(256), 0, s, a); break;
+            case 32: hipLaunchKernelGGL((conv_x6_kernel<3, 3, 4, 32>), dim3(grid), dim3(256), 0, s, a); break;
+            case 40: hipLaunchKernelGGL((conv_x6_kernel<3, 3, 4, 40>), dim3(grid), dim3(256), 0, s, a); break;
+            default: hipLaunchKernelGGL((conv_x6_kernel<KH, KW, 4>), dim3(grid), dim3(256), 0, s, a); break;
+            }
+        } else
+            hipLaunchKernelGGL((conv_x6_kernel<KH, KW, 4>), dim3(grid), dim3(256), 0, s, a);
+        break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

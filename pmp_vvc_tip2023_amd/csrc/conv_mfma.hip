@@ -323,7 +323,7 @@ hipError_t launch_conv_mfma(hipStream_t s, const ConvMfmaArgs &a)
     if ((a.H & 15) || (a.W & 15) || (a.Cin & 15) || (a.Cout & 15) || (a.x_sc && (a.Csc & 15)) || a.N <= 0)
         return hipErrorInvalidValue;
     if (a.pool && a.gate) return hipErrorInvalidValue;
-    const int v = g_conv_variant;
+    const int v = g_conv_variant > 2 ? 2 : g_conv_variant;
     if (a.KH == 3 && a.KW == 3)
         return v == 0 ? launch_k<3, 3, 0, 1>(s, a) : (v == 1 ? launch_k<3, 3, 1, 3>(s, a) : launch_k<3, 3, 2, 2>(s, a));
     if (a.KH == 5 && a.KW == 5)

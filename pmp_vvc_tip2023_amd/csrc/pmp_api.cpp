@@ -449,7 +449,7 @@ int pmp_write_partition_file(const char *path, int frames, int H, int W, const u
 
 int pmp_debug_set_conv_variant(int variant)
 {
-    if (variant < 0 || variant > 2) return set_err(nullptr, PMP_E_INVALID, "pmp_debug_set_conv_variant: 0..2");
+    if (variant < 0 || variant > 64) return set_err(nullptr, PMP_E_INVALID, "pmp_debug_set_conv_variant: 0..2 (10+bits: timing-only bf16x6 ablations)");
     g_conv_variant = variant;
     return PMP_OK;
 }

@@ -4,9 +4,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pmp_vvc_tip2023_amd import engine
 eng = engine.Engine(0)
 shapes = [(256, 64, 64, 64, 64, 3), (256, 64, 64, 64, 64, 5), (256, 64, 64, 32, 64, 5), (512, 32, 32, 64, 64, 3), (512, 16, 16, 64, 32, 3), (512, 16, 16, 32, 16, 3)]
-if len(sys.argv) > 1:
+abl = [0]
+if len(sys.argv) > 1 and sys.argv[1] == "ablate":
+    shapes = [(256, 64, 64, 64, 64, 3)]
+    abl = [0, 1, 8, 32, 40]      # bits: 1 staging, 2 weight loads, 4 x reads, 8 epilogue, 16 barrier
+elif len(sys.argv) > 1:
     shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
-for (n, h, w, ci, co, k) in shapes:
+for ab in abl:
+  eng.lib.pmp_debug_set_conv_variant(10 + ab if ab else 2)
+  for (n, h, w, ci, co, k) in shapes:
+    if ab: print("ablation bits", ab, end=": ")
     a, b, d, r = C.c_double(), C.c_double(), C.c_double(), C.c_double()
     eng._ck(eng.lib.pmp_debug_conv_bench(eng.h, n, h, w, ci, co, k, 10, C.byref(a), C.byref(b), C.byref(d), C.byref(r)))
     fl = 2.0 * n * h * w * co * ci * k * k
