@@ -82,30 +82,21 @@ __device__ __forceinline__ void x6_stage_load(const StagePlan<KH, KW> &p, const 
 }
 
 template <int KH, int KW>
-__device__ __forceinline__ void x6_stage_store(const StagePlan<KH, KW> &p, u32x4 *lds, const u32x4 (&r)[GeoX<KH, KW>::NLD],
-                                               int k0 = 0, int k1 = 1 << 20)
+__device__ __forceinline__ void x6_stage_store(const StagePlan<KH, KW> &p, u32x4 *lds, const u32x4 (&r)[GeoX<KH, KW>::NLD])
 {
     typedef GeoX<KH, KW> G;
 #pragma unroll
     for (int k = 0; k < G::NLD; ++k) {
-        if (k < k0 || k >= k1) continue;
         const int i = threadIdx.x + k * 256;
         const u32x4 z = {0u, 0u, 0u, 0u};
         if (i < G::PIECES) lds[i] = ((p.valid >> k) & 1u) ? r[k] : z;   // LDS image: [split][pixel][2 halves], linear
     }
 }
 
-// Accumulates one source (all channel groups) of ONE output tile.  Tiles are chained: while the last channel group of
-// this tile computes, channel group 0 of the workgroup's NEXT tile (n2, ty2, tx2) is staged into the other LDS buffer and
-// the weight stream wraps around to K-step 0, so the next call starts with `prestaged` = true and issues MFMAs at once.
-// (Ablation, tools/conv_x6_bench.py: one tile per workgroup spent ~15 % of its life in slot turnover - store
-//  acknowledgement, then an un-overlapped HBM round trip for the first halo tile.)
 template <int KH, int KW, int NT, int ABL = 0>
 __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__ x, size_t plane_stride,
                                               const unsigned short *__restrict__ wpk, int C, int H, int W, int n, int ty,
-                                              int tx, u32x4 *lds, f32x4 (&acc)[4][NT], bool prestaged, int &par,
-                                              bool has_next, int n2, int ty2, int tx2, bf16x8 (&w0)[NT], bf16x8 (&w1)[NT],
-                                              bf16x8 (&w2)[NT], StagePlan<KH, KW> &plan)
+                                              int tx, u32x4 *lds, f32x4 (&acc)[4][NT])
 {
     typedef GeoX<KH, KW> G;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, xl = lane & 15, g = lane >> 4;
@@ -113,17 +104,12 @@ __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__
     const size_t grp_sz = (size_t)H * W * 16;
     const unsigned short *grp0 = x + (size_t)n * CB * grp_sz;
     u32x4 r[G::NLD];
-    const bf16x8 *wl = reinterpret_cast<const bf16x8 *>(wpk) + lane;
-    const int last = CB * G::NKS - 1;
-    if (!prestaged) {
-        x6_plan<KH, KW>(plan, plane_stride, H, W, ty, tx);
-        __syncthreads();  // LDS may still be read by a previous source
-        x6_stage_load<KH, KW>(plan, grp0, r);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) { w2[nt] = wl[(2 * NT + nt) * 64]; w1[nt] = wl[(1 * NT + nt) * 64]; w0[nt] = wl[(0 * NT + nt) * 64]; }
-        x6_stage_store<KH, KW>(plan, lds + (par & 1) * G::PIECES, r);
-        __syncthreads();
-    }
+    StagePlan<KH, KW> plan;
+    x6_plan<KH, KW>(plan, plane_stride, H, W, ty, tx);
+    __syncthreads();
+    x6_stage_load<KH, KW>(plan, grp0, r);
+    x6_stage_store<KH, KW>(plan, lds, r);
+    __syncthreads();
     // ---- K-step schedule -------------------------------------------------------------------------------------
     // Weight fragments live in ONE register set that is refilled in place, split by split, as soon as its last MFMA
     // of the K-step has been issued: w2 is used once (with x0), w1 twice, w0 three times, so the products are ordered
@@ -132,16 +118,17 @@ __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__
     //   phase C: x0*w0, x1*w0, x2*w0 -> request next w0
     // Every request has at least one full phase (256..768 MFMA cycles) before its first use.  All loads are
     // unconditional so hipcc's s_waitcnt vmcnt(N) are exact counts; scheduling fences pin the phase order.
+    const bf16x8 *wl = reinterpret_cast<const bf16x8 *>(wpk) + lane;
+    const int last = CB * G::NKS - 1;
+    bf16x8 w0[NT], w1[NT], w2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { w2[nt] = wl[(2 * NT + nt) * 64]; w1[nt] = wl[(1 * NT + nt) * 64]; w0[nt] = wl[(0 * NT + nt) * 64]; }
     const int pb = ((wave * 4 * G::TW + xl) * 2 + (g & 1)) * 16;   // bytes inside a split plane, tap (0,0)
     constexpr int PER = (G::NLD + G::NKS - 1) / G::NKS;            // staging loads issued per K-step
     for (int cb = 0; cb < CB; ++cb) {
-        const bool lastg = cb + 1 == CB;
-        const bool more = !lastg || has_next;
-        // next halo tile: this tile's next channel group, or group 0 of the chained tile; clamped so loads stay unconditional
-        const unsigned short *nxt_grp = (lastg && has_next) ? x + (size_t)n2 * CB * grp_sz
-                                                            : ((ABL & 32) ? x : grp0) + (size_t)min(cb + 1, CB - 1) * grp_sz;
-        if (lastg && has_next) x6_plan<KH, KW>(plan, plane_stride, H, W, ty2, tx2);
-        const char *buf = reinterpret_cast<const char *>(lds + ((par + cb) & 1) * G::PIECES);
+        const bool more = cb + 1 < CB;
+        const unsigned short *nxt_grp = ((ABL & 32) ? x : grp0) + (size_t)min(cb + 1, CB - 1) * grp_sz;   // clamped: loads stay unconditional
+        const char *buf = reinterpret_cast<const char *>(lds + (cb & 1) * G::PIECES);
         bf16x8 xa[4], xb[4], x1[4], x2[4];   // x0 fragments alternate between xa (even K-steps) and xb (odd)
 #pragma unroll
         for (int m = 0; m < 4; ++m) xa[m] = *reinterpret_cast<const bf16x8 *>(buf + pb + ((g >> 1) ? ((1 / KW) * G::TW + 1 % KW) * 32 * (G::TAPS > 1) : 0) + m * G::TW * 32);
@@ -150,8 +137,7 @@ __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__
             const int t0 = 2 * ks, t1 = (2 * ks + 1 < G::TAPS) ? 2 * ks + 1 : 2 * ks;
             const int o0 = ((t0 / KW) * G::TW + t0 % KW) * 32, o1 = ((t1 / KW) * G::TW + t1 % KW) * 32;
             const char *px = buf + pb + ((g >> 1) ? o1 : o0);
-            int nxt = cb * G::NKS + ks + 1;
-            if (nxt > last) nxt = has_next ? 0 : last;   // chained tiles: the weight stream wraps to K-step 0
+            const int nxt = min(cb * G::NKS + ks + 1, last);
             const bf16x8 *wk = wl + (size_t)nxt * (3 * NT * 64);
             bf16x8 (&x0)[4] = (ks & 1) ? xb : xa;
             bf16x8 (&x0n)[4] = (ks & 1) ? xa : xb;
@@ -161,12 +147,7 @@ __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__
 #pragma unroll
                 for (int m = 0; m < 4; ++m) x2[m] = *reinterpret_cast<const bf16x8 *>(px + 2 * G::PLANE * 16 + m * G::TW * 32);
             }
-            // rolling staging: the slice requested in the previous K-step is written to the OTHER LDS buffer (nobody reads
-            // it during this group), then this K-step's slice is requested - only two slices are live in registers.
-            if (!(ABL & 1)) {
-                if (ks > 0 && more) x6_stage_store<KH, KW>(plan, lds + ((par + cb + 1) & 1) * G::PIECES, r, (ks - 1) * PER, ks * PER);
-                x6_stage_load<KH, KW>(plan, nxt_grp, r, ks * PER, (ks + 1) * PER);
-            }
+            if (!(ABL & 1)) x6_stage_load<KH, KW>(plan, nxt_grp, r, ks * PER, (ks + 1) * PER);
             __builtin_amdgcn_sched_barrier(0);
             // phase A
 #pragma unroll
@@ -215,11 +196,10 @@ __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__
         }
         // NKS is odd for every kernel size used (1, 5, 13): the last K-step read x0 from xa, as the next group's first will
         static_assert(G::NKS % 2 == 1, "x0 register alternation assumes an odd number of K-steps per channel group");
-        if (more && !(ABL & 1)) x6_stage_store<KH, KW>(plan, lds + ((par + cb + 1) & 1) * G::PIECES, r, (G::NKS - 1) * PER, G::NLD);
+        if (more && !(ABL & 1)) x6_stage_store<KH, KW>(plan, lds + ((cb + 1) & 1) * G::PIECES, r);
         if (!(ABL & 16))
         __syncthreads();
     }
-    par = (par + CB) & 1;
 }
 
 __device__ __forceinline__ f32x4 load_split4(const unsigned short *p, size_t plane_stride)
@@ -248,18 +228,9 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(ConvX6Args a)
 {
     typedef GeoX<KH, KW> G;
     __shared__ u32x4 lds[2 * G::PIECES];
-    const int tiles_x = a.W >> 4, tiles = tiles_x * (a.H >> 4), ntiles = a.N * tiles;
+    const int tiles_x = a.W >> 4, tiles = tiles_x * (a.H >> 4);
+    const int n = blockIdx.x / tiles, t = blockIdx.x - n * tiles, ty = t / tiles_x, tx = t - ty * tiles_x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, xl = lane & 15, g = lane >> 4;
-    const bool chain = a.x_sc == nullptr;   // the 1x1 shortcut source re-uses the LDS buffers: no cross-tile prefetch then
-    bf16x8 w0[NT], w1[NT], w2[NT];
-    StagePlan<KH, KW> plan;
-    int par = 0;
-    bool prestaged = false;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int n = tile / tiles, t = tile - n * tiles, ty = t / tiles_x, tx = t - ty * tiles_x;
-    const int tile2 = tile + gridDim.x;
-    const bool has_next = chain && tile2 < ntiles;
-    const int n2 = tile2 / tiles, t2 = tile2 - n2 * tiles, ty2 = t2 / tiles_x, tx2 = t2 - ty2 * tiles_x;
 
     f32x4 acc[4][NT];
 #pragma unroll
@@ -267,16 +238,8 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(ConvX6Args a)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    x6_accumulate<KH, KW, NT, ABL>(a.x, a.x_stride, a.w, a.Cin, a.H, a.W, n, ty, tx, lds, acc, prestaged, par, has_next, n2, ty2,
-                                   tx2, w0, w1, w2, plan);
-    prestaged = has_next;
-    if (a.x_sc) {
-        bf16x8 s0[NT], s1[NT], s2[NT];
-        StagePlan<1, 1> splan;
-        int spar = 0;
-        x6_accumulate<1, 1, NT>(a.x_sc, a.sc_stride, a.w_sc, a.Csc, a.H, a.W, n, ty, tx, lds, acc, false, spar, false, 0, 0, 0, s0,
-                                s1, s2, splan);
-    }
+    x6_accumulate<KH, KW, NT, ABL>(a.x, a.x_stride, a.w, a.Cin, a.H, a.W, n, ty, tx, lds, acc);
+    if (a.x_sc) x6_accumulate<1, 1, NT>(a.x_sc, a.sc_stride, a.w_sc, a.Csc, a.H, a.W, n, ty, tx, lds, acc);
 
     const int H = a.H, W = a.W;
     const size_t grp = (size_t)H * W * 16;
@@ -287,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(ConvX6Args a)
 #pragma unroll
             for (int m = 0; m < 4; ++m) sacc += acc[m][nt].x + acc[m][nt].y + acc[m][nt].z + acc[m][nt].w;
         if (sacc == 123.456f) a.out[0] = 1;
-        continue;
+        return;
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -326,16 +289,13 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(ConvX6Args a)
                 }
             }
         }
-        __builtin_amdgcn_sched_barrier(0);   // keep the epilogue's loads/stores of one cout tile together (register pressure)
     }
-    }  // tile loop
 }
 
 template <int KH, int KW>
 static hipError_t launch_x6(hipStream_t s, const ConvX6Args &a)
 {
-    // persistent workgroups: 2 per CU (VGPR-limited), each walks tiles blockIdx.x, blockIdx.x + grid, ...
-    const int ntiles = a.N * (a.H >> 4) * (a.W >> 4), grid = ntiles < 512 ? ntiles : 512;
+    const int grid = a.N * (a.H >> 4) * (a.W >> 4);
     switch (a.Cout >> 4) {
     case 1: hipLaunchKernelGGL((conv_x6_kernel<KH, KW, 1>), dim3(grid), dim3(256), 0, s, a); break;
     case 2: hipLaunchKernelGGL((conv_x6_kernel<KH, KW, 2>), dim3(grid), dim3(256), 0, s, a); break;
