@@ -25,7 +25,11 @@ import numpy as np
 import torch
 
 FLOP_PER_BLOCK = {"Luma": 6.991e9, "Chroma": 2.300e9}      # conv MACs x 2, QT + MTT
-PEAK_FP32_MFMA_TFLOPS = 157.3                                # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 peak
+# Peak of the datapath actually used: the exact-fp32 MFMA, or the dense bf16 MFMA peak divided by the six
+# bf16 products the 3-term split spends per fp32 product (MI355X_MICROARCH.md: 157.3 TF fp32 matrix, ~2.5 PF bf16 dense).
+PEAK_TFLOPS = {"fp32": 157.3, "bf16x6": 2500.0 / 6.0}
+PEAK_NOTE = {"fp32": "v_mfma_f32_16x16x4_f32 peak 157.3 TFLOP/s",
+             "bf16x6": "bf16 dense MFMA peak 2500 TFLOP/s / 6 products per fp32-accurate product = 416.7"}
 DOMINANT = "conv_mfma_3x3_c64"                               # 3x3 64->64 convs: 57.8 % of the MTT-net FLOPs
 
 
@@ -81,6 +85,8 @@ def main():
     ap.add_argument("--qp", type=int, default=22)
     ap.add_argument("--chunk", type=int, default=0, help="blocks per pass inside the library (0 = library default)")
     ap.add_argument("--cpu-sample", type=int, default=512, help="blocks for the CPU baseline (0 = skip)")
+    ap.add_argument("--precision", default="bf16x6", choices=["bf16x6", "fp32"],
+                    help="conv datapath: 3-term bf16 split (6 MFMA products, fp32-equivalent) or exact fp32 MFMA")
     ap.add_argument("--breakdown", action="store_true", help="extra pass with every kernel class timed (stderr)")
     args = ap.parse_args()
 
@@ -107,6 +113,7 @@ def main():
     eng = engine.Engine(local_rank)
     if args.chunk:
         eng.set_chunk(args.chunk)
+    eng.set_precision(args.precision)
     eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     eng.load(args.comp, args.qp)
     log("rank %d: weights %s" % (rank, {k[0]: v for k, v in eng.provenance.items()}))
@@ -163,11 +170,12 @@ def main():
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.isfile(tp):
             try:
-                traffic = json.load(open(tp)).get(DOMINANT)
+                traffic = json.load(open(tp)).get(DOMINANT + ":" + args.precision)
             except Exception:
                 traffic = None
-        roof = {"bound": "mfma", "kernel": DOMINANT, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+        peak = PEAK_TFLOPS[args.precision]
+        roof = {"bound": "mfma", "kernel": DOMINANT, "achieved": round(achieved, 2), "peak": round(peak, 1),
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "peak_basis": PEAK_NOTE[args.precision],
                 "launches": launches, "avg_launch_ms": round(ms / launches, 4),
                 "flop_per_launch": flops / launches}
 
@@ -188,11 +196,13 @@ def main():
             "metric": "CTUs/sec (luma QT+MTT inference+post-proc)", "value": round(blocks_per_s / 4.0, 2), "unit": "CTU/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16x6", "data": "synthetic",
             "config": {"workload": "%s QT+MTT nets QP%d, batch=%d synthetic 64x64 blocks (68x68 u8 inputs) per GPU, "
                                    "device-resident infer+Map2Partition; CTU = 128x128 = 4 blocks" % (args.comp, args.qp, n),
                        "blocks_per_gpu": n, "global_blocks": n * n_gpus, "parallelism": "dp%d (blocks sharded, gather of split flags to rank 0)" % n_gpus,
-                       "weights": "QT real (reference trained_models), MTT synthetic seed=qp"},
+                       "weights": "QT real (reference trained_models), MTT synthetic seed=qp",
+                       "datapath": "fp32 MFMA" if args.precision == "fp32" else
+                                   "bf16 MFMA, every fp32 operand split into 3 bf16 terms, 6 products, fp32 accumulate (fp32-equivalent logits)"},
             "blocks_per_s": round(blocks_per_s, 1),
             "net_tflops": round(blocks_per_s * FLOP_PER_BLOCK[args.comp] / 1e12, 2),
             "roofline": roof,

@@ -16,22 +16,9 @@
 // 16 channels x a PAIR of taps: lane group g = l>>4 reads channels 8(g&1)..+7 of tap 2p+(g>>1).  An odd tap count pads
 // the last pair with zero weights (3x3: 10 % padding, 5x5: 4 %).
 #include "pmp_kernels.h"
+#include "split3.h"
 
 namespace pmp {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void split3(float v, __bf16 &a, __bf16 &b, __bf16 &c)
-{
-    a = (__bf16)v;
-    const float r1 = v - (float)a;   // exact
-    b = (__bf16)r1;
-    const float r2 = r1 - (float)b;  // exact
-    c = (__bf16)r2;                  // exact: at most 8 significant bits are left
-}
 
 template <int KH, int KW>
 struct GeoX {
@@ -200,27 +187,6 @@ __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__
         if (!(ABL & 16))
         __syncthreads();
     }
-}
-
-__device__ __forceinline__ f32x4 load_split4(const unsigned short *p, size_t plane_stride)
-{
-    // 4 consecutive channels of one pixel from the three planes, summed exactly back to fp32
-    const bf16x4 a = *reinterpret_cast<const bf16x4 *>(p), b = *reinterpret_cast<const bf16x4 *>(p + plane_stride),
-                 c = *reinterpret_cast<const bf16x4 *>(p + 2 * plane_stride);
-    f32x4 v;
-    v.x = ((float)a.x + (float)b.x) + (float)c.x; v.y = ((float)a.y + (float)b.y) + (float)c.y;
-    v.z = ((float)a.z + (float)b.z) + (float)c.z; v.w = ((float)a.w + (float)b.w) + (float)c.w;
-    return v;
-}
-
-__device__ __forceinline__ void store_split4(unsigned short *p, size_t plane_stride, f32x4 v)
-{
-    __bf16 a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3;
-    split3(v.x, a0, b0, c0); split3(v.y, a1, b1, c1); split3(v.z, a2, b2, c2); split3(v.w, a3, b3, c3);
-    const bf16x4 a = {a0, a1, a2, a3}, b = {b0, b1, b2, b3}, c = {c0, c1, c2, c3};
-    *reinterpret_cast<bf16x4 *>(p) = a;
-    *reinterpret_cast<bf16x4 *>(p + plane_stride) = b;
-    *reinterpret_cast<bf16x4 *>(p + 2 * plane_stride) = c;
 }
 
 template <int KH, int KW, int NT, int ABL = 0>

@@ -1,10 +1,9 @@
 // conv_misc.hip — the non-MFMA kernels of the four nets: stems straight from the u8 blocks, the tiny tail convs,
 // the heads, and the gather-style glue (multi-scale pool concat, attention inputs).  Together < 3 % of the FLOPs.
 #include "pmp_kernels.h"
+#include "split3.h"
 
 namespace pmp {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ size_t act_idx(int n, int c, int y, int x, int CB, int H, int W)
 {
@@ -22,12 +21,13 @@ __device__ __forceinline__ size_t act_idx(int n, int c, int y, int x, int CB, in
 //   chroma MSBD : 4 planes 36x36, conv 5x5 -> 16, 3x5 -> 8, 5x3 -> 8  (Model_QBD.py:228-233)
 // Right/bottom zero padding of 4 (2) is common to all convs: the (5,9) conv pads right only but never reads below
 // row y+4 <= 67, the (9,5) conv pads bottom only but never reads right of x+4 <= 67.
-template <int KH, int KW, int CIN, int PS, int ROWS>
+template <int KH, int KW, int CIN, int PS, int ROWS, bool SPLIT>
 __device__ __forceinline__ void stem_conv(const float *__restrict__ planes, const float *__restrict__ w,
                                           const float *__restrict__ bias, int cout, int x, int y0, int OUT,
-                                          float *__restrict__ out_n, int ch_off)
+                                          const ActOut &out, size_t out_n, int ch_off)
 {
     // planes: [CIN][PS][PS];  w: [KH*KW][CIN][cout];  computes rows y0..y0+ROWS-1 at column x for all cout.
+#pragma unroll 1
     for (int c0 = 0; c0 < cout; c0 += 8) {
         float acc[ROWS][8];
 #pragma unroll
@@ -60,16 +60,16 @@ __device__ __forceinline__ void stem_conv(const float *__restrict__ planes, cons
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             const int c = ch_off + c0;  // 8 consecutive channels inside one 16-channel group
-            float *o = out_n + (((size_t)(c >> 4) * OUT + (y0 + r)) * OUT + x) * 16 + (c & 15);
+            const size_t o = out_n + (((size_t)(c >> 4) * OUT + (y0 + r)) * OUT + x) * 16 + (c & 15);
             f32x4 v0 = {fmaxf(acc[r][0], 0.f), fmaxf(acc[r][1], 0.f), fmaxf(acc[r][2], 0.f), fmaxf(acc[r][3], 0.f)};
             f32x4 v1 = {fmaxf(acc[r][4], 0.f), fmaxf(acc[r][5], 0.f), fmaxf(acc[r][6], 0.f), fmaxf(acc[r][7], 0.f)};
-            *reinterpret_cast<f32x4 *>(o) = v0;
-            *reinterpret_cast<f32x4 *>(o + 4) = v1;
+            if (SPLIT) { store_split4(out.s3 + o, out.stride, v0); store_split4(out.s3 + o + 4, out.stride, v1); }
+            else { *reinterpret_cast<f32x4 *>(out.f32 + o) = v0; *reinterpret_cast<f32x4 *>(out.f32 + o + 4) = v1; }
         }
     }
 }
 
-template <bool LUMA, bool MSBD>
+template <bool LUMA, bool MSBD, bool SPLIT>
 __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
 {
     constexpr int S = LUMA ? 68 : 34, P = LUMA ? 4 : 2, PS = S + P, OUT = S - P;  // 72/36 planes, 64/32 outputs
@@ -112,18 +112,19 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
     }
     __syncthreads();
 
-    float *out_n = a.out + (size_t)n * 2 * OUT * OUT * 16;
+    const size_t out_n = (size_t)n * 2 * OUT * OUT * 16;
+    const ActOut out{a.out, a.out_s3, a.s3_stride};
     constexpr int COLS_PER_WG = 256 / OUT;       // luma: 4 row-bands of 16 rows; chroma: 8 bands of 4 rows
     constexpr int BAND = OUT / COLS_PER_WG;
     const int x = tid % OUT, band = tid / OUT;
     for (int y0 = band * BAND; y0 < (band + 1) * BAND; y0 += 4) {
         if (MSBD) {
-            stem_conv<K1, K1, CIN, PS, 4>(planes, wl, bl, 16, x, y0, OUT, out_n, 0);
-            stem_conv<K2, K1, CIN, PS, 4>(planes, wl + K1 * K1 * CIN * 16, bl + 16, 8, x, y0, OUT, out_n, 16);
-            stem_conv<K1, K2, CIN, PS, 4>(planes, wl + K1 * K1 * CIN * 16 + K2 * K1 * CIN * 8, bl + 24, 8, x, y0, OUT,
-                                          out_n, 24);
+            stem_conv<K1, K1, CIN, PS, 4, SPLIT>(planes, wl, bl, 16, x, y0, OUT, out, out_n, 0);
+            stem_conv<K2, K1, CIN, PS, 4, SPLIT>(planes, wl + K1 * K1 * CIN * 16, bl + 16, 8, x, y0, OUT, out, out_n, 16);
+            stem_conv<K1, K2, CIN, PS, 4, SPLIT>(planes, wl + K1 * K1 * CIN * 16 + K2 * K1 * CIN * 8, bl + 24, 8, x, y0, OUT,
+                                          out, out_n, 24);
         } else {
-            stem_conv<K1, K1, CIN, PS, 4>(planes, wl, bl, 32, x, y0, OUT, out_n, 0);
+            stem_conv<K1, K1, CIN, PS, 4, SPLIT>(planes, wl, bl, 32, x, y0, OUT, out, out_n, 0);
         }
     }
 }
@@ -136,7 +137,8 @@ static hipError_t launch_stem_t(hipStream_t s, const StemArgs &a)
     constexpr int K1 = LUMA ? 9 : 5, K2 = LUMA ? 5 : 3;
     constexpr int NW = MSBD ? (K1 * K1 * CIN * 16 + 2 * K2 * K1 * CIN * 8) : (K1 * K1 * CIN * 32);
     const size_t smem = (size_t)(CIN * PS * PS + NW + 32) * sizeof(float);
-    hipLaunchKernelGGL((stem_kernel<LUMA, MSBD>), dim3(a.N), dim3(256), smem, s, a);
+    if (a.out_s3) hipLaunchKernelGGL((stem_kernel<LUMA, MSBD, true>), dim3(a.N), dim3(256), smem, s, a);
+    else hipLaunchKernelGGL((stem_kernel<LUMA, MSBD, false>), dim3(a.N), dim3(256), smem, s, a);
     return hipGetLastError();
 }
 
@@ -237,10 +239,10 @@ hipError_t launch_head(hipStream_t s, const HeadArgs &a)
 
 // =============================================================================================== glue
 // cat[x5, up2(mp2(x5)), up4(mp4(x5)), up8(mp8(x5))]: one workgroup per (block, 16-channel group of x5).
-__global__ __launch_bounds__(256) void multipool_concat_kernel(const float *__restrict__ x5, float *__restrict__ x6)
+__global__ __launch_bounds__(256) void multipool_concat_kernel(const float *__restrict__ x5, ActOut x6)
 {
-    __shared__ float t[16 * 16 * 16];
-    __shared__ float p2[8 * 8 * 16], p4[4 * 4 * 16], p8[2 * 2 * 16];
+    __shared__ __attribute__((aligned(16))) float t[16 * 16 * 16];
+    __shared__ __attribute__((aligned(16))) float p2[8 * 8 * 16], p4[4 * 4 * 16], p8[2 * 2 * 16];
     const int n = blockIdx.x >> 1, cb = blockIdx.x & 1, tid = threadIdx.x;
     const float *src = x5 + ((size_t)n * 2 + cb) * 4096;
     for (int i = tid; i < 4096; i += 256) t[i] = src[i];
@@ -263,25 +265,25 @@ __global__ __launch_bounds__(256) void multipool_concat_kernel(const float *__re
         p8[tid] = fmaxf(fmaxf(q[0], q[16]), fmaxf(q[64], q[80]));
     }
     __syncthreads();
-    float *dst = x6 + (size_t)n * 8 * 4096;  // channel groups: x5 -> 0,1; mp2 -> 2,3; mp4 -> 4,5; mp8 -> 6,7
-    for (int i = tid; i < 4096; i += 256) {
+    const size_t dst = (size_t)n * 8 * 4096;  // channel groups: x5 -> 0,1; mp2 -> 2,3; mp4 -> 4,5; mp8 -> 6,7
+    for (int i = tid * 4; i < 4096; i += 1024) {   // 4 consecutive channels per thread and step
         const int c = i & 15, x = (i >> 4) & 15, y = i >> 8;
-        dst[(size_t)(0 + cb) * 4096 + i] = t[i];
-        dst[(size_t)(2 + cb) * 4096 + i] = p2[((y >> 1) * 8 + (x >> 1)) * 16 + c];
-        dst[(size_t)(4 + cb) * 4096 + i] = p4[((y >> 2) * 4 + (x >> 2)) * 16 + c];
-        dst[(size_t)(6 + cb) * 4096 + i] = p8[((y >> 3) * 2 + (x >> 3)) * 16 + c];
+        x6.store4(dst + (size_t)(0 + cb) * 4096 + i, *reinterpret_cast<const f32x4 *>(t + i));
+        x6.store4(dst + (size_t)(2 + cb) * 4096 + i, *reinterpret_cast<const f32x4 *>(p2 + ((y >> 1) * 8 + (x >> 1)) * 16 + c));
+        x6.store4(dst + (size_t)(4 + cb) * 4096 + i, *reinterpret_cast<const f32x4 *>(p4 + ((y >> 2) * 4 + (x >> 2)) * 16 + c));
+        x6.store4(dst + (size_t)(6 + cb) * 4096 + i, *reinterpret_cast<const f32x4 *>(p8 + ((y >> 3) * 2 + (x >> 3)) * 16 + c));
     }
 }
 
-hipError_t launch_multipool_concat(hipStream_t s, const float *x5, float *x6, int N)
+hipError_t launch_multipool_concat(hipStream_t s, const float *x5, float *x6, int N, unsigned short *x6_s3, size_t s3_stride)
 {
-    hipLaunchKernelGGL(multipool_concat_kernel, dim3(N * 2), dim3(256), 0, s, x5, x6);
+    hipLaunchKernelGGL(multipool_concat_kernel, dim3(N * 2), dim3(256), 0, s, x5, ActOut{x6, x6_s3, s3_stride});
     return hipGetLastError();
 }
 
 __global__ __launch_bounds__(256) void att_input_kernel(const float *__restrict__ q, const float *__restrict__ bt,
-                                                        const float *__restrict__ dire, int layer,
-                                                        float *__restrict__ out, int N, int S)
+                                                        const float *__restrict__ dire, int layer, ActOut out, int N,
+                                                        int S)
 {
     const size_t total = (size_t)N * S * S;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -291,16 +293,15 @@ __global__ __launch_bounds__(256) void att_input_kernel(const float *__restrict_
     const size_t o = ((size_t)n * 3 + layer) * 256 + (y / sh) * 16 + (x / sh);
     f32x4 v = {q[(size_t)n * 64 + (y / sq) * 8 + (x / sq)], bt[o], dire[o], 0.f};
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    f32x4 *dst = reinterpret_cast<f32x4 *>(out + i * 16);
-    dst[0] = v; dst[1] = z; dst[2] = z; dst[3] = z;
+    out.store4(i * 16, v); out.store4(i * 16 + 4, z); out.store4(i * 16 + 8, z); out.store4(i * 16 + 12, z);
 }
 
 hipError_t launch_att_input(hipStream_t s, const float *q, const float *bt, const float *dire, int layer, float *out,
-                            int N, int S)
+                            int N, int S, unsigned short *out_s3, size_t s3_stride)
 {
     const size_t total = (size_t)N * S * S;
-    hipLaunchKernelGGL(att_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, q, bt, dire, layer, out,
-                       N, S);
+    hipLaunchKernelGGL(att_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, q, bt, dire, layer,
+                       ActOut{out, out_s3, s3_stride}, N, S);
     return hipGetLastError();
 }
 

@@ -133,9 +133,9 @@ struct Graph {
     Act stem(bool luma, bool msbd, const uint8_t *by, const uint8_t *bu, const uint8_t *bv, const float *q)
     {
         const int S = luma ? 64 : 32;
-        Act o = alloc(32, S, S, false);
+        Act o = alloc(32, S, S, x6());     // bf16x6 mode: the stem writes split-3 planes directly
         if (!live()) return o;
-        StemArgs a{by, bu, bv, q, w.stem_w, w.stem_b, o.p, n};
+        StemArgs a{by, bu, bv, q, w.stem_w, w.stem_b, o.split ? nullptr : o.p, n, o.split ? o.s() : nullptr, o.stride};
         const int cin = (luma ? 1 : 3) + (msbd ? 1 : 0), k1 = luma ? 9 : 5, k2 = luma ? 5 : 3;
         const double macs = msbd ? (double)cin * (k1 * k1 * 16 + 2 * k1 * k2 * 8) : (double)cin * k1 * k1 * 32;
         KScope ks(c, K_STEM, 2.0 * n * S * S * macs);
@@ -163,10 +163,10 @@ int forward_q(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, con
     Act x3 = g.rb(x2, "resblock_q1", luma);            // luma: + max_pool2d(2); chroma: no pool (:179)
     Act x4 = g.rb(x3, "resblock_q2", true);
     Act x5 = g.rb(x4, "resblock_q3", false, nullptr, true);   // fp32: read by the multi-scale pool kernel
-    Act x6 = g.alloc(128, 16, 16, false);
+    Act x6 = g.alloc(128, 16, 16, g.x6());
     if (g.live()) {
         KScope ks(c, K_SMALL, 0.0);
-        g.check(launch_multipool_concat(c->stream, x5.p, x6.p, n), "multipool_concat");
+        g.check(launch_multipool_concat(c->stream, x5.p, x6.split ? nullptr : x6.p, n, x6.split ? x6.s() : nullptr, x6.stride), "multipool_concat");
     }
     Act x7 = g.rb(x6, "resblock_q4");
     Act x8 = g.rb(x7, "resblock_q5", true, nullptr, true);    // fp32: 8x8 tail runs on the direct kernel
@@ -191,19 +191,19 @@ int forward_msbd(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, 
     Act b = g.rb(g.rb(g.rb(x5, "trunk_B1.0"), "trunk_B1.1"), "trunk_B1.2", false, nullptr, true);
     g.head(b, 0, 0, nullptr, bt, dire);
     // attention 1 gates x5 (:140-143), branch B2 -> out1 (accumulated in the head kernel, :146)
-    Act ai = g.alloc(16, 16, 16, false);
+    Act ai = g.alloc(16, 16, 16, g.x6());
     if (g.live()) {
         KScope ks(c, K_SMALL, 0.0);
-        g.check(launch_att_input(c->stream, qt, bt, dire, 0, ai.p, n, 16), "att_input");
+        g.check(launch_att_input(c->stream, qt, bt, dire, 0, ai.split ? nullptr : ai.p, n, 16, ai.split ? ai.s() : nullptr, ai.stride), "att_input");
     }
     Act xb1 = g.rb(g.rb(ai, "trunk_Att1.0"), "trunk_Att1.1", false, &x5);
     b = g.rb(g.rb(g.rb(xb1, "trunk_B2.0"), "trunk_B2.1"), "trunk_B2.2", false, nullptr, true);
     g.head(b, 1, 1, nullptr, bt, dire);
     // attention 2 gates x4 at 32x32 (:147-150), branch B3 -> pool -> out2 (:151-153)
-    Act aj = g.alloc(16, 32, 32, false);
+    Act aj = g.alloc(16, 32, 32, g.x6());
     if (g.live()) {
         KScope ks(c, K_SMALL, 0.0);
-        g.check(launch_att_input(c->stream, qt, bt, dire, 1, aj.p, n, 32), "att_input");
+        g.check(launch_att_input(c->stream, qt, bt, dire, 1, aj.split ? nullptr : aj.p, n, 32, aj.split ? aj.s() : nullptr, aj.stride), "att_input");
     }
     Act xb3 = g.rb(g.rb(aj, "trunk_Att2.0"), "trunk_Att2.1", false, &x4);
     b = g.rb(g.rb(g.rb(xb3, "trunk_B3.0"), "trunk_B3.1"), "trunk_B3.2", true, nullptr, true);

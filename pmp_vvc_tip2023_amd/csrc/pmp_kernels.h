@@ -58,6 +58,7 @@ struct StemArgs {
     const float *bias;   // [32]
     float *out;
     int N;
+    unsigned short *out_s3; size_t s3_stride;   // if out_s3 != nullptr the 32 channels are written as split-3 planes
 };
 hipError_t launch_stem(hipStream_t s, bool luma, bool msbd, const StemArgs &a);
 
@@ -85,12 +86,13 @@ struct HeadArgs {
 hipError_t launch_head(hipStream_t s, const HeadArgs &a);
 
 // x5 [N][2][16][16][16] -> cat[x5, up2(mp2), up4(mp4), up8(mp8)] [N][8][16][16][16]  (Model_QBD.py:84-87)
-hipError_t launch_multipool_concat(hipStream_t s, const float *x5, float *x6, int N);
+hipError_t launch_multipool_concat(hipStream_t s, const float *x5, float *x6, int N, unsigned short *x6_s3 = nullptr,
+                                   size_t s3_stride = 0);
 
 // Attention trunk input (Model_QBD.py:140, :147): [N][1][S][S][16] with ch0 = up(q) (S/8 nearest), ch1 = bt[n][layer],
 // ch2 = dire[n][layer] (both 16x16, nearest-upsampled to S), channels 3..15 zero.
 hipError_t launch_att_input(hipStream_t s, const float *q, const float *bt, const float *dire, int layer, float *out,
-                            int N, int S);
+                            int N, int S, unsigned short *out_s3 = nullptr, size_t s3_stride = 0);
 
 // 2x2 max-pool on a blocked activation (only used where the pool cannot ride a conv epilogue).
 hipError_t launch_maxpool2(hipStream_t s, const float *x, float *out, int N, int C, int H, int W);

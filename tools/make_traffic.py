@@ -5,10 +5,14 @@ FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half the bytes o
 import json, sys
 src = json.load(open(sys.argv[1]))
 out = {}
+import os
+if os.path.isfile("profiles/pmc_traffic.json"):
+    out = json.load(open("profiles/pmc_traffic.json"))
 for k, v in src.items():
-    if k.startswith("conv_mfma_kernel<3, 3, 4") and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-        out["conv_mfma_3x3_c64"] = round((2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0)
-        out["_detail"] = {"kernel": k, "FETCH_SIZE_KB": v["FETCH_SIZE"], "WRITE_SIZE_KB": v["WRITE_SIZE"],
+    mode = "fp32" if k.startswith("conv_mfma_kernel<3, 3, 4") else ("bf16x6" if k.startswith("conv_x6_kernel<3, 3, 4") else None)
+    if mode and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        out["conv_mfma_3x3_c64:" + mode] = round((2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0)
+        out["_detail:" + mode] = {"kernel": k, "FETCH_SIZE_KB": v["FETCH_SIZE"], "WRITE_SIZE_KB": v["WRITE_SIZE"],
                           "note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024, averaged over the launches of the kernel"}
 json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
 print(out)
