@@ -15,6 +15,8 @@
 // GEMM mapping: D[cout][pixel], A = weights, B = pixels (as conv_mfma.hip).  One MFMA K-step (K = 32) covers
 // 16 channels x a PAIR of taps: lane group g = l>>4 reads channels 8(g&1)..+7 of tap 2p+(g>>1).  An odd tap count pads
 // the last pair with zero weights (3x3: 10 % padding, 5x5: 4 %).
+#include <type_traits>
+
 #include "pmp_kernels.h"
 #include "split3.h"
 
@@ -105,27 +107,53 @@ __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__
     //   phase C: x0*w0, x1*w0, x2*w0 -> request next w0
     // Every request has at least one full phase (256..768 MFMA cycles) before its first use.  All loads are
     // unconditional so hipcc's s_waitcnt vmcnt(N) are exact counts; scheduling fences pin the phase order.
+    // Tap pairing.  A K-step covers 16 channels x 2 taps.  With an odd tap count the last tap has no partner inside its
+    // channel group; when the number of groups is even ("paired" packing, see pack_x6) the last tap of an EVEN group is
+    // deferred and paired with the last tap of the following ODD group - both halo tiles are resident then, the even one
+    // in the other LDS buffer - so no MFMA work is spent on zero padding (3x3: 9 K-steps per two groups instead of 10).
+    //   mode 0 (plain): NKS = ceil(T/2) per group, last pair padded with zero weights
+    //   mode 1 (even group of a pair): (T-1)/2 K-steps;  mode 2 (odd group): (T-1)/2 + 1 K-steps
+    const bool paired = (CB & 1) == 0 && (G::TAPS & 1);
     const bf16x8 *wl = reinterpret_cast<const bf16x8 *>(wpk) + lane;
-    const int last = CB * G::NKS - 1;
+    const int last = paired ? (CB / 2) * G::TAPS - 1 : CB * G::NKS - 1;   // last K-step of the weight stream
     bf16x8 w0[NT], w1[NT], w2[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { w2[nt] = wl[(2 * NT + nt) * 64]; w1[nt] = wl[(1 * NT + nt) * 64]; w0[nt] = wl[(0 * NT + nt) * 64]; }
     const int pb = ((wave * 4 * G::TW + xl) * 2 + (g & 1)) * 16;   // bytes inside a split plane, tap (0,0)
-    constexpr int PER = (G::NLD + G::NKS - 1) / G::NKS;            // staging loads issued per K-step
-    for (int cb = 0; cb < CB; ++cb) {
+    int stream = 0;                                                  // K-step index inside the weight stream
+    int tapsel = g >> 1;
+
+    auto group = [&](auto mode_tag, int cb) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr int NK = MODE == 0 ? G::NKS : (MODE == 1 ? (G::TAPS - 1) / 2 : (G::TAPS - 1) / 2 + 1);
+        constexpr int PER = NK > 0 ? (G::NLD + NK - 1) / NK : G::NLD;   // staging loads issued per K-step
         const bool more = cb + 1 < CB;
         const unsigned short *nxt_grp = ((ABL & 32) ? x : grp0) + (size_t)min(cb + 1, CB - 1) * grp_sz;   // clamped: loads stay unconditional
         const char *buf = reinterpret_cast<const char *>(lds + (cb & 1) * G::PIECES);
+        const char *prv = reinterpret_cast<const char *>(lds + ((cb + 1) & 1) * G::PIECES);
+        // per-lane address of this lane's tap of K-step ks (lanes g < 2: first tap of the pair, g >= 2: second)
+        auto xaddr = [&](int ks) -> const char * {
+            int tA = 2 * ks, tB = 2 * ks + 1;
+            bool prevA = false;
+            if (MODE == 0 && tB >= G::TAPS) tB = tA;
+            if (MODE == 2 && ks == NK - 1) { tA = tB = G::TAPS - 1; prevA = true; }
+            const int oA = ((tA / KW) * G::TW + tA % KW) * 32, oB = ((tB / KW) * G::TW + tB % KW) * 32;
+            return (tapsel ? buf + oB : (prevA ? prv : buf) + oA) + pb;
+        };
         bf16x8 xa[4], xb[4], x1[4], x2[4];   // x0 fragments alternate between xa (even K-steps) and xb (odd)
+        if (NK == 0) {   // 1x1 source, even group: nothing to compute yet, only fetch the partner group
+            if (!(ABL & 1)) x6_stage_load<KH, KW>(plan, nxt_grp, r);
+        } else {
+            const char *p0 = xaddr(0);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) xa[m] = *reinterpret_cast<const bf16x8 *>(buf + pb + ((g >> 1) ? ((1 / KW) * G::TW + 1 % KW) * 32 * (G::TAPS > 1) : 0) + m * G::TW * 32);
+            for (int m = 0; m < 4; ++m) xa[m] = *reinterpret_cast<const bf16x8 *>(p0 + m * G::TW * 32);
+        }
 #pragma unroll
-        for (int ks = 0; ks < G::NKS; ++ks) {
-            const int t0 = 2 * ks, t1 = (2 * ks + 1 < G::TAPS) ? 2 * ks + 1 : 2 * ks;
-            const int o0 = ((t0 / KW) * G::TW + t0 % KW) * 32, o1 = ((t1 / KW) * G::TW + t1 % KW) * 32;
-            const char *px = buf + pb + ((g >> 1) ? o1 : o0);
-            const int nxt = min(cb * G::NKS + ks + 1, last);
-            const bf16x8 *wk = wl + (size_t)nxt * (3 * NT * 64);
+        for (int ks = 0; ks < NK; ++ks) {
+            asm volatile("" : "+v"(tapsel));   // keeps hipcc from hoisting every K-step's tap offset out of the group loop
+            const char *px = xaddr(ks);
+            ++stream;
+            const bf16x8 *wk = wl + (size_t)min(stream, last) * (3 * NT * 64);
             bf16x8 (&x0)[4] = (ks & 1) ? xb : xa;
             bf16x8 (&x0n)[4] = (ks & 1) ? xa : xb;
             if (!(ABL & 4) || ks == 0) {
@@ -158,10 +186,8 @@ __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) w1[nt] = wk[(1 * NT + nt) * 64];
             }
-            if (ks + 1 < G::NKS && !(ABL & 4)) {
-                const int u0 = 2 * ks + 2, u1 = (2 * ks + 3 < G::TAPS) ? 2 * ks + 3 : 2 * ks + 2;
-                const int q0 = ((u0 / KW) * G::TW + u0 % KW) * 32, q1 = ((u1 / KW) * G::TW + u1 % KW) * 32;
-                const char *pn = buf + pb + ((g >> 1) ? q1 : q0);
+            if (ks + 1 < NK && !(ABL & 4)) {
+                const char *pn = xaddr(ks + 1);
 #pragma unroll
                 for (int m = 0; m < 4; ++m) x0n[m] = *reinterpret_cast<const bf16x8 *>(pn + m * G::TW * 32);
             }
@@ -181,11 +207,18 @@ __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        // NKS is odd for every kernel size used (1, 5, 13): the last K-step read x0 from xa, as the next group's first will
-        static_assert(G::NKS % 2 == 1, "x0 register alternation assumes an odd number of K-steps per channel group");
+        // the partner buffer is only overwritten here, after the last K-step that may read the previous group from it
         if (more && !(ABL & 1)) x6_stage_store<KH, KW>(plan, lds + ((cb + 1) & 1) * G::PIECES, r);
-        if (!(ABL & 16))
-        __syncthreads();
+        if (!(ABL & 16)) __syncthreads();
+    };
+
+    if (paired) {
+        for (int cb = 0; cb < CB; cb += 2) {
+            group(std::integral_constant<int, 1>{}, cb);
+            group(std::integral_constant<int, 2>{}, cb + 1);
+        }
+    } else {
+        for (int cb = 0; cb < CB; ++cb) group(std::integral_constant<int, 0>{}, cb);
     }
 }
 

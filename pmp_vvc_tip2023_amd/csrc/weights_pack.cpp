@@ -4,6 +4,7 @@
 // mis-shaped tensor is an error (the reference silently keeps random init for such tensors, which would be a
 // silent accuracy bug here).
 #include <cstring>
+#include <utility>
 
 #include "pmp_host.h"
 
@@ -91,30 +92,45 @@ static inline float bf16_f32(unsigned short h)
     return f;
 }
 
-// OIHW conv weight -> split-3 bf16 MFMA A-operand fragments (conv_bf16x6.hip):
-// [Cin_pad/16][ceil(taps/2)][3 splits][Cout_pad/16][64 lanes][8]; lane l of cout-tile nt holds
-// W[cout = 16nt + (l&15)][channel = 16cb + 8((l>>4)&1) + j][tap = 2ks + (l>>5)], zero beyond the last tap.
+// OIHW conv weight -> split-3 bf16 MFMA A-operand fragments (conv_bf16x6.hip), one K-step = 16 channels x 2 taps:
+// [K-step][3 splits][Cout_pad/16][64 lanes][8]; lane l of cout-tile nt holds W[cout = 16nt + (l&15)][channel = 16cb +
+// 8((l>>4)&1) + j][tap], where (cb, tap) of the lane's half (l>>5) follows the kernel's K-step order:
+//   plain  (odd number of channel groups, or even tap count): per group ceil(T/2) K-steps (2ks, 2ks+1), zero beyond T;
+//   paired (even number of groups, odd T): group 2p: (T-1)/2 K-steps (2ks, 2ks+1); group 2p+1: the same, then one K-step
+//          pairing tap T-1 of group 2p (lanes l<32) with tap T-1 of group 2p+1 (lanes l>=32).
 std::vector<unsigned short> pack_x6(const float *w, int cout, int cin, int kh, int kw, int cout_pad, int cin_pad)
 {
-    const int taps = kh * kw, nks = (taps + 1) / 2, CB = cin_pad / 16, NT = cout_pad / 16;
-    std::vector<unsigned short> out((size_t)CB * nks * 3 * NT * 64 * 8, 0);
-    for (int cb = 0; cb < CB; ++cb)
-        for (int ks = 0; ks < nks; ++ks)
-            for (int nt = 0; nt < NT; ++nt)
-                for (int l = 0; l < 64; ++l)
-                    for (int j = 0; j < 8; ++j) {
-                        const int co = nt * 16 + (l & 15), g = l >> 4, ci = cb * 16 + 8 * (g & 1) + j, t = 2 * ks + (g >> 1);
-                        float v = 0.f;
-                        if (co < cout && ci < cin && t < taps) v = w[((size_t)co * cin + ci) * taps + t];
-                        const unsigned short h0 = bf16_rne(v);
-                        const float r1 = v - bf16_f32(h0);
-                        const unsigned short h1 = bf16_rne(r1);
-                        const float r2 = r1 - bf16_f32(h1);
-                        const unsigned short h2 = bf16_rne(r2);
-                        const unsigned short hs[3] = {h0, h1, h2};
-                        for (int sp = 0; sp < 3; ++sp)
-                            out[(((((size_t)cb * nks + ks) * 3 + sp) * NT + nt) * 64 + l) * 8 + j] = hs[sp];
-                    }
+    const int taps = kh * kw, CB = cin_pad / 16, NT = cout_pad / 16;
+    const bool paired = (CB % 2 == 0) && (taps % 2 == 1);
+    struct Half { int cb, tap; };
+    std::vector<std::pair<Half, Half>> steps;
+    if (paired) {
+        for (int cb = 0; cb < CB; ++cb) {
+            for (int ks = 0; ks < (taps - 1) / 2; ++ks) steps.push_back({{cb, 2 * ks}, {cb, 2 * ks + 1}});
+            if (cb & 1) steps.push_back({{cb - 1, taps - 1}, {cb, taps - 1}});
+        }
+    } else {
+        for (int cb = 0; cb < CB; ++cb)
+            for (int ks = 0; ks < (taps + 1) / 2; ++ks) steps.push_back({{cb, 2 * ks}, {cb, 2 * ks + 1}});   // tap >= T -> zeros
+    }
+    std::vector<unsigned short> out(steps.size() * 3 * NT * 64 * 8, 0);
+    for (size_t st = 0; st < steps.size(); ++st)
+        for (int nt = 0; nt < NT; ++nt)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int g = l >> 4;
+                    const Half h = (g >> 1) ? steps[st].second : steps[st].first;
+                    const int co = nt * 16 + (l & 15), ci = h.cb * 16 + 8 * (g & 1) + j, t = h.tap;
+                    float v = 0.f;
+                    if (co < cout && ci < cin && t < taps) v = w[((size_t)co * cin + ci) * taps + t];
+                    const unsigned short h0 = bf16_rne(v);
+                    const float r1 = v - bf16_f32(h0);
+                    const unsigned short h1 = bf16_rne(r1);
+                    const float r2 = r1 - bf16_f32(h1);
+                    const unsigned short h2 = bf16_rne(r2);
+                    const unsigned short hs[3] = {h0, h1, h2};
+                    for (int sp = 0; sp < 3; ++sp) out[(((st * 3 + sp) * NT + nt) * 64 + l) * 8 + j] = hs[sp];
+                }
     return out;
 }
 
