@@ -305,31 +305,4 @@ hipError_t launch_att_input(hipStream_t s, const float *q, const float *bt, cons
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void maxpool2_kernel(const float *__restrict__ x, float *__restrict__ out, size_t total,
-                                                       int H, int W)
-{
-    // one thread per output float4: index = ((plane*Ho + yo)*Wo + xo)*4 + s
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int Ho = H >> 1, Wo = W >> 1;
-    const int s = (int)(i & 3);
-    size_t r = i >> 2;
-    const int xo = (int)(r % Wo); r /= Wo;
-    const int yo = (int)(r % Ho);
-    const size_t plane = r / Ho;
-    const f32x4 *p = reinterpret_cast<const f32x4 *>(x) + ((plane * H + 2 * yo) * W + 2 * xo) * 4 + s;
-    const f32x4 a = p[0], b = p[4], c = p[(size_t)W * 4], d = p[(size_t)W * 4 + 4];
-    f32x4 v;
-    v.x = fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, d.x)); v.y = fmaxf(fmaxf(a.y, b.y), fmaxf(c.y, d.y));
-    v.z = fmaxf(fmaxf(a.z, b.z), fmaxf(c.z, d.z)); v.w = fmaxf(fmaxf(a.w, b.w), fmaxf(c.w, d.w));
-    reinterpret_cast<f32x4 *>(out)[i] = v;
-}
-
-hipError_t launch_maxpool2(hipStream_t s, const float *x, float *out, int N, int C, int H, int W)
-{
-    const size_t total = (size_t)N * (C >> 4) * (H >> 1) * (W >> 1) * 4;
-    hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, out, total, H, W);
-    return hipGetLastError();
-}
-
 }  // namespace pmp

@@ -94,9 +94,6 @@ hipError_t launch_multipool_concat(hipStream_t s, const float *x5, float *x6, in
 hipError_t launch_att_input(hipStream_t s, const float *q, const float *bt, const float *dire, int layer, float *out,
                             int N, int S, unsigned short *out_s3 = nullptr, size_t s3_stride = 0);
 
-// 2x2 max-pool on a blocked activation (only used where the pool cannot ride a conv epilogue).
-hipError_t launch_maxpool2(hipStream_t s, const float *x, float *out, int N, int C, int H, int W);
-
 // ------------------------------------------------------------------------------------------------ post-processing
 // eli_structual_error + Map_to_Partition, one wavefront per block.  qt raw logits [N][64]; bt, dire [N][3][256].
 hipError_t launch_postprocess(hipStream_t s, const float *qt, const float *bt, const float *dire, int64_t N,

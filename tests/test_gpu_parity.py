@@ -268,3 +268,25 @@ def test_driver_end_to_end_files(eng, oracle_lib, tmp_path):
                 assert open(got, "rb").read() == open(po, "rb").read(), (name, comp, qp)
     rows = open(out / "j1" / "Time_Sta_0_2.txt").read().strip().split("\n")
     assert len(rows) == 2 * 4 and all(r.count(",") == 5 for r in rows)
+
+
+def test_config4_4k_frame_sharded_equals_unsharded(eng, oracle_lib):
+    """BASELINE.json configs[3] on one GPU: a synthetic 3840x2160 frame (1980 blocks).  Processing the block stream in the
+    contiguous shards 8 ranks would take (parallel.shard_bounds) and concatenating the records gives the same bytes as
+    one pass - the multi-GPU path has no cross-block dependency - and the emitted file passes the format invariants."""
+    from pmp_vvc_tip2023_amd import engine as E, parallel, synth
+    y, u, v = synth.recipe_r_frames(1, 2160, 3840, 4)
+    by, bu, bv = eng.output_block_yuv(y, u, v, 8)
+    n = by.shape[0]
+    assert n == 60 * 33
+    for comp, qp in (("Luma", 32), ("Chroma", 27)):
+        whole = parallel.pack_records(*eng.infer_postprocess(comp, qp, by, bu, bv))
+        parts = []
+        for r in range(8):
+            lo, hi = parallel.shard_bounds(n, r, 8)
+            parts.append(parallel.pack_records(*eng.infer_postprocess(comp, qp, by[lo:hi], bu[lo:hi], bv[lo:hi])))
+        assert np.array_equal(np.concatenate(parts), whole)
+        h, vv, q8, d8 = parallel.unpack_records(whole)
+        text = E.format_partition_text(1, 2160, 3840, h, vv, q8, d8)
+        assert text.count(b"\n") == 5 * (33 * 16) * (60 * 16) + (33 * 8) * (60 * 8)
+        assert h.reshape(33, 60, 16, 16)[:, :, 0, :].all() and vv.reshape(33, 60, 16, 16)[:, :, :, 0].all()
