@@ -48,7 +48,7 @@ def cpu_baseline(sample_blocks, seed):
     x = O.luma_input(y)
     # torch's CPU convs do not scale to hundreds of threads on 64x64 maps: calibrate the thread count on 8 blocks
     best = (None, 1e30)
-    for th in sorted({min(ncpu, t) for t in (8, 16, 32, 64, ncpu)}):
+    for th in sorted({min(ncpu, t) for t in (8, 16, 32, 64)}):   # hundreds of threads run at < 1 block/s: not probed
         torch.set_num_threads(th)
         O.infer_qbd(wq, wbd, x[:8], True, batch=8)           # warm-up (oneDNN primitive creation)
         t = time.perf_counter()
