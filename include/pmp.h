@@ -69,7 +69,7 @@ int pmp_destroy(pmp_ctx *ctx);
 int pmp_set_stream(pmp_ctx *ctx, void *hip_stream);
 int pmp_synchronize(pmp_ctx *ctx);
 
-/* Blocks processed per pass (activation workspace is sized for it); n > chunk is looped.  Default 1024. */
+/* Blocks processed per pass (activation workspace is sized for it); n > chunk is looped.  1..4096, default 1024. */
 int pmp_set_chunk(pmp_ctx *ctx, int blocks);
 
 /* Convolution datapath.  Both are fp32-accurate; results differ in the last bits only.

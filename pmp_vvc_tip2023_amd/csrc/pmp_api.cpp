@@ -208,7 +208,7 @@ int pmp_synchronize(pmp_ctx *c) { CHECK_CTX(c); return sync(c); }
 int pmp_set_chunk(pmp_ctx *c, int blocks)
 {
     CHECK_CTX(c);
-    if (blocks < 1 || blocks > 65536) return set_err(c, PMP_E_INVALID, "pmp_set_chunk: 1..65536");
+    if (blocks < 1 || blocks > 4096) return set_err(c, PMP_E_INVALID, "pmp_set_chunk: 1..4096");   // 32-bit element offsets inside one activation tensor
     c->chunk = blocks;
     return PMP_OK;
 }
