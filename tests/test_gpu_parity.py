@@ -290,3 +290,23 @@ def test_config4_4k_frame_sharded_equals_unsharded(eng, oracle_lib):
         text = E.format_partition_text(1, 2160, 3840, h, vv, q8, d8)
         assert text.count(b"\n") == 5 * (33 * 16) * (60 * 16) + (33 * 8) * (60 * 8)
         assert h.reshape(33, 60, 16, 16)[:, :, 0, :].all() and vv.reshape(33, 60, 16, 16)[:, :, :, 0].all()
+
+
+def test_end_to_end_flags_vs_reference_logits(eng, g1, oracle_lib):
+    """End-to-end audit ('bit-exact flags is only well-defined for identical logits'): split flags
+    from the HIP path (own logits) against flags the oracle derives from the REFERENCE's logits (G1/G2, torch CPU).
+    |logit difference| is ~1e-5, so a pooled cell would have to sit that close to a .5 rounding boundary to flip;
+    on the golden set none does, in either datapath."""
+    g2 = golden("g2_msbd.npz")
+    mism = total = 0
+    for comp in ("Luma", "Chroma"):
+        for qp in (22, 27, 32, 37):
+            hor, ver, q8, d8 = eng.infer_postprocess(comp, qp, g1["block_y"][:8], g1["block_u"][:8], g1["block_v"][:8])
+            qt_ref = g1["qt_%s_%d" % (comp, qp)][:8]
+            bt_ref = np.stack([g2["out%d_%s_%d" % (k, comp, qp)][:, 0] for k in range(3)], 1)
+            dr_ref = np.stack([g2["out%d_%s_%d" % (k, comp, qp)][:, 1] for k in range(3)], 1)
+            oh, ov, oq, od = oracle_lib.seq_post_process(qt_ref, bt_ref, dr_ref, comp, 1, 64 * 8, 64, None)
+            mism += int((hor != oh).sum() + (ver != ov).sum() + (q8 != oq.astype(np.uint8)).sum() + (d8 != od).sum())
+            total += hor.size + ver.size + q8.size + d8.size
+    assert total == 8 * 8 * 1344
+    assert mism == 0, "%d of %d emitted values differ from the reference-logit path" % (mism, total)
