@@ -114,7 +114,11 @@ def main():
     if args.chunk:
         eng.set_chunk(args.chunk)
     eng.set_precision(args.precision)
-    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    # One explicit side stream for everything in a step: the library's launches, the record packing and the RCCL gather
+    # are ordered on it (torch's default stream has handle 0, which pmp_set_stream reads as "use the context's own").
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    eng.set_stream(stream.cuda_stream)
     eng.load(args.comp, args.qp)
     log("rank %d: weights %s" % (rank, {k[0]: v for k, v in eng.provenance.items()}))
 
