@@ -28,8 +28,10 @@ FLOP_PER_BLOCK = {"Luma": 6.991e9, "Chroma": 2.300e9}      # con
 # Peak of the datapath actually used: the exact-fp32 MFMA, or the dense bf16 MFMA peak divided by the six
 # bf16 products the 3-term split spends per fp32 product (MI355X_MICROARCH.md: 157.3 TF fp32 matrix, ~2.5 PF bf16 dense).
 PEAK_TFLOPS = {"fp32": 157.3, "bf16x6": 2500.0 / 6.0}
-PEAK_NOTE = {"fp32": "v_mfma_f32_16x16x4_f32 peak 157.3 TFLOP/s",
-             "bf16x6": "bf16 dense MFMA peak 2500 TFLOP/s / 6 products per fp32-accurate product = 416.7"}
+PEAK_NOTE = {"fp32": "v_mfma_f32_16x16x4_f32 peak 157.3 TFLOP/s (register-resident loop on this pool: 154.7)",
+             "bf16x6": "bf16 dense MFMA peak 2500 TFLOP/s / 6 products per fp32-accurate product = 416.7 "
+                       "(register-resident bf16 loop on this pool sustains 1925 TFLOP/s at 1.97 GHz = 320.9 per fp32 product, "
+                       "profiles/r01_mfma_peak_microbench.txt)"}
 DOMINANT = "conv_mfma_3x3_c64"                               # 3x3 64->64 convs: 57.8 % of the MTT-net FLOPs
 
 
