@@ -103,13 +103,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():          # smoke tests: several ranks on one GPU (gloo)
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if n_gpus > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("PMP_DIST_BACKEND", "nccl")     # "nccl" = RCCL; "gloo" only to smoke-test the control flow
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from pmp_vvc_tip2023_amd import engine, synth
     eng = engine.Engine(local_rank)
@@ -143,7 +149,11 @@ def main():
         if n_gpus > 1:
             # the path's only exchange: split flags of every shard go to rank 0, which owns the file writer
             res[:, :256] = hor; res[:, 256:512] = ver; res[:, 512:576] = q8; res[:, 576:] = d8.view(torch.uint8)
-            dist.gather(res, list(gathered.split(n)) if rank == 0 else None, dst=0)
+            if dist.get_backend() == "nccl":
+                dist.gather(res, list(gathered.split(n)) if rank == 0 else None, dst=0)
+            else:
+                rc = res.cpu()
+                dist.gather(rc, [torch.empty_like(rc) for _ in range(world)] if rank == 0 else None, dst=0)
 
     for _ in range(args.warmup):
         step()
@@ -163,7 +173,7 @@ def main():
     kt = eng.ktime()
     eng.ktime_enable(0)
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
