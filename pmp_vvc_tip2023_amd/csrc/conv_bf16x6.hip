@@ -22,6 +22,17 @@
 
 namespace pmp {
 
+// In-kernel stamps (diagnostic builds only, ABL bit 128): shader-clock ticks of wave 0 at phase boundaries, written to a
+// debug buffer nothing else reads (cdna guide, 'In-kernel stamps').
+__device__ __forceinline__ unsigned long long stamp_now()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+
 template <int KH, int KW>
 struct GeoX {
     static constexpr int TH = 16 + KH - 1, TW = 16 + KW - 1, TAPS = KH * KW, NKS = (TAPS + 1) / 2;
@@ -85,9 +96,11 @@ __device__ __forceinline__ void x6_stage_store(const StagePlan<KH, KW> &p, u32x4
 template <int KH, int KW, int NT, int ABL = 0>
 __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__ x, size_t plane_stride,
                                               const unsigned short *__restrict__ wpk, int C, int H, int W, int n, int ty,
-                                              int tx, u32x4 *lds, f32x4 (&acc)[4][NT])
+                                              int tx, u32x4 *lds, f32x4 (&acc)[4][NT], unsigned long long *dbg = nullptr)
 {
     typedef GeoX<KH, KW> G;
+    unsigned long long t_pro = 0, t_k = 0, t_s = 0, tmark = 0;   // diagnostic accumulators (ABL & 128)
+    if (ABL & 128) tmark = stamp_now();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, xl = lane & 15, g = lane >> 4;
     const int CB = C >> 4;
     const size_t grp_sz = (size_t)H * W * 16;
@@ -99,6 +112,7 @@ __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__
     x6_stage_load<KH, KW>(plan, grp0, r);
     x6_stage_store<KH, KW>(plan, lds, r);
     __syncthreads();
+    if (ABL & 128) { const unsigned long long t = stamp_now(); t_pro = t - tmark; tmark = t; }
     // ---- K-step schedule -------------------------------------------------------------------------------------
     // Weight fragments live in ONE register set that is refilled in place, split by split, as soon as its last MFMA
     // of the K-step has been issued: w2 is used once (with x0), w1 twice, w0 three times, so the products are ordered
@@ -207,9 +221,11 @@ __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (ABL & 128) { const unsigned long long t = stamp_now(); t_k += t - tmark; tmark = t; }
         // the partner buffer is only overwritten here, after the last K-step that may read the previous group from it
         if (more && !(ABL & 1)) x6_stage_store<KH, KW>(plan, lds + ((cb + 1) & 1) * G::PIECES, r);
         if (!(ABL & 16)) __syncthreads();
+        if (ABL & 128) { const unsigned long long t = stamp_now(); t_s += t - tmark; tmark = t; }
     };
 
     if (paired) {
@@ -220,6 +236,7 @@ __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__
     } else {
         for (int cb = 0; cb < CB; ++cb) group(std::integral_constant<int, 0>{}, cb);
     }
+    if ((ABL & 128) && dbg && threadIdx.x == 0) { dbg[0] = t_pro; dbg[1] = t_k; dbg[2] = t_s; }
 }
 
 template <int KH, int KW, int NT, int ABL = 0>
@@ -237,7 +254,9 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(ConvX6Args a)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    x6_accumulate<KH, KW, NT, ABL>(a.x, a.x_stride, a.w, a.Cin, a.H, a.W, n, ty, tx, lds, acc);
+    const unsigned long long t_begin = (ABL & 128) ? stamp_now() : 0;
+    x6_accumulate<KH, KW, NT, ABL>(a.x, a.x_stride, a.w, a.Cin, a.H, a.W, n, ty, tx, lds, acc, a.dbg ? a.dbg + (size_t)blockIdx.x * 8 : nullptr);
+    const unsigned long long t_acc = (ABL & 128) ? stamp_now() : 0;
     if (a.x_sc) x6_accumulate<1, 1, NT>(a.x_sc, a.sc_stride, a.w_sc, a.Csc, a.H, a.W, n, ty, tx, lds, acc);
 
     const int H = a.H, W = a.W;
@@ -289,6 +308,12 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(ConvX6Args a)
             }
         }
     }
+    if ((ABL & 128) && a.dbg && threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // include the store acknowledgements in the epilogue span
+        const unsigned long long t_end = stamp_now();
+        unsigned long long *d = a.dbg + (size_t)blockIdx.x * 8;
+        d[3] = t_acc - t_begin; d[4] = t_end - t_acc; d[5] = t_begin;
+    }
 }
 
 template <int KH, int KW>
@@ -310,6 +335,7 @@ static hipError_t launch_x6(hipStream_t s, const ConvX6Args &a)
             case 31: hipLaunchKernelGGL((conv_x6_kernel<3, 3, 4, 31>), dim3(grid), dim3(256), 0, s, a); break;
             case 32: hipLaunchKernelGGL((conv_x6_kernel<3, 3, 4, 32>), dim3(grid), dim3(256), 0, s, a); break;
             case 40: hipLaunchKernelGGL((conv_x6_kernel<3, 3, 4, 40>), dim3(grid), dim3(256), 0, s, a); break;
+            case 128: hipLaunchKernelGGL((conv_x6_kernel<3, 3, 4, 128>), dim3(grid), dim3(256), 0, s, a); break;
             default: hipLaunchKernelGGL((conv_x6_kernel<KH, KW, 4>), dim3(grid), dim3(256), 0, s, a); break;
             }
         } else

@@ -449,7 +449,7 @@ int pmp_write_partition_file(const char *path, int frames, int H, int W, const u
 
 int pmp_debug_set_conv_variant(int variant)
 {
-    if (variant < 0 || variant > 64) return set_err(nullptr, PMP_E_INVALID, "pmp_debug_set_conv_variant: 0..2 (10+bits: timing-only bf16x6 ablations)");
+    if (variant < 0 || variant > 255) return set_err(nullptr, PMP_E_INVALID, "pmp_debug_set_conv_variant: 0..2 (10+bits: timing-only bf16x6 ablations)");
     g_conv_variant = variant;
     return PMP_OK;
 }
@@ -500,6 +500,29 @@ int pmp_debug_conv_bench(pmp_ctx *c, int n, int h, int w, int cin, int cout, int
         for (int i = 0; i < iters; ++i) launch_conv_x6(c->stream, b);
         hipEventRecord(e1, c->stream); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
         if (ms_x6) *ms_x6 = ms / iters;
+        if (g_conv_variant == 10 + 128 && k == 3 && cout == 64) {   // in-kernel stamp report (diagnostic build)
+            const int wgs = n * (h / 16) * (w / 16);
+            unsigned long long *ddbg = nullptr;
+            if (hipMalloc((void **)&ddbg, (size_t)wgs * 8 * 8) == hipSuccess) {
+                hipMemset(ddbg, 0, (size_t)wgs * 8 * 8);
+                b.dbg = ddbg;
+                launch_conv_x6(c->stream, b);
+                hipStreamSynchronize(c->stream);
+                std::vector<unsigned long long> hd((size_t)wgs * 8);
+                hipMemcpy(hd.data(), ddbg, hd.size() * 8, hipMemcpyDeviceToHost);
+                double s[5] = {0, 0, 0, 0, 0};
+                unsigned long long tmin = ~0ull, tmax = 0;
+                for (int i = 0; i < wgs; ++i) {
+                    for (int j = 0; j < 5; ++j) s[j] += (double)hd[(size_t)i * 8 + j];
+                    if (hd[(size_t)i * 8 + 5] < tmin) tmin = hd[(size_t)i * 8 + 5];
+                    if (hd[(size_t)i * 8 + 5] + hd[(size_t)i * 8 + 3] + hd[(size_t)i * 8 + 4] > tmax) tmax = hd[(size_t)i * 8 + 5] + hd[(size_t)i * 8 + 3] + hd[(size_t)i * 8 + 4];
+                }
+                fprintf(stderr, "stamps (mean ticks per workgroup, wave 0): prologue %.0f | K-steps %.0f | staging store+barrier %.0f | accumulate total %.0f | epilogue %.0f | launch span %.0f\n",
+                        s[0] / wgs, s[1] / wgs, s[2] / wgs, s[3] / wgs, s[4] / wgs, (double)(tmax - tmin));
+                b.dbg = nullptr;
+                hipFree(ddbg);
+            }
+        }
         launch_split3_to_f32(c->stream, dys, dy2, ny, ny);
         std::vector<float> y1(ny), y2(ny);
         hipMemcpyAsync(y1.data(), dy, ny * 4, hipMemcpyDeviceToHost, c->stream);

@@ -41,6 +41,7 @@ struct ConvX6Args {
     float *out_f32;
     int N, H, W, Cin, Csc, Cout, KH, KW;
     int relu, pool;
+    unsigned long long *dbg;   // diagnostic builds only: 8 stamps per workgroup (nullptr otherwise)
 };
 hipError_t launch_conv_x6(hipStream_t s, const ConvX6Args &a);
 hipError_t launch_f32_to_split3(hipStream_t s, const float *x, unsigned short *out, size_t n, size_t plane_stride);
