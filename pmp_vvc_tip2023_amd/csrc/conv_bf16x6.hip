@@ -99,7 +99,7 @@ __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__
                                               int tx, u32x4 *lds, f32x4 (&acc)[4][NT], unsigned long long *dbg = nullptr)
 {
     typedef GeoX<KH, KW> G;
-    unsigned long long t_pro = 0, t_k = 0, t_s = 0, tmark = 0;   // diagnostic accumulators (ABL & 128)
+    unsigned long long t_pro = 0, t_k = 0, t_s = 0, t_w = 0, t_b = 0, tmark = 0;   // diagnostic accumulators (ABL & 128)
     if (ABL & 128) tmark = stamp_now();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, xl = lane & 15, g = lane >> 4;
     const int CB = C >> 4;
@@ -223,9 +223,11 @@ __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__
         }
         if (ABL & 128) { const unsigned long long t = stamp_now(); t_k += t - tmark; tmark = t; }
         // the partner buffer is only overwritten here, after the last K-step that may read the previous group from it
+        if ((ABL & 128) && more) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long t = stamp_now(); t_w += t - tmark; tmark = t; }
         if (more && !(ABL & 1)) x6_stage_store<KH, KW>(plan, lds + ((cb + 1) & 1) * G::PIECES, r);
+        if (ABL & 128) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t = stamp_now(); t_s += t - tmark; tmark = t; }
         if (!(ABL & 16)) __syncthreads();
-        if (ABL & 128) { const unsigned long long t = stamp_now(); t_s += t - tmark; tmark = t; }
+        if (ABL & 128) { const unsigned long long t = stamp_now(); t_b += t - tmark; tmark = t; }
     };
 
     if (paired) {
@@ -236,7 +238,7 @@ __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__
     } else {
         for (int cb = 0; cb < CB; ++cb) group(std::integral_constant<int, 0>{}, cb);
     }
-    if ((ABL & 128) && dbg && threadIdx.x == 0) { dbg[0] = t_pro; dbg[1] = t_k; dbg[2] = t_s; }
+    if ((ABL & 128) && dbg && threadIdx.x == 0) { dbg[0] = t_pro; dbg[1] = t_k; dbg[2] = t_s; dbg[6] = t_w; dbg[7] = t_b; }
 }
 
 template <int KH, int KW, int NT, int ABL = 0>

@@ -510,15 +510,16 @@ int pmp_debug_conv_bench(pmp_ctx *c, int n, int h, int w, int cin, int cout, int
                 hipStreamSynchronize(c->stream);
                 std::vector<unsigned long long> hd((size_t)wgs * 8);
                 hipMemcpy(hd.data(), ddbg, hd.size() * 8, hipMemcpyDeviceToHost);
-                double s[5] = {0, 0, 0, 0, 0};
+                double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 unsigned long long tmin = ~0ull, tmax = 0;
                 for (int i = 0; i < wgs; ++i) {
-                    for (int j = 0; j < 5; ++j) s[j] += (double)hd[(size_t)i * 8 + j];
+                    for (int j = 0; j < 8; ++j) if (j != 5) s[j] += (double)hd[(size_t)i * 8 + j];
                     if (hd[(size_t)i * 8 + 5] < tmin) tmin = hd[(size_t)i * 8 + 5];
                     if (hd[(size_t)i * 8 + 5] + hd[(size_t)i * 8 + 3] + hd[(size_t)i * 8 + 4] > tmax) tmax = hd[(size_t)i * 8 + 5] + hd[(size_t)i * 8 + 3] + hd[(size_t)i * 8 + 4];
                 }
-                fprintf(stderr, "stamps (mean ticks per workgroup, wave 0): prologue %.0f | K-steps %.0f | staging store+barrier %.0f | accumulate total %.0f | epilogue %.0f | launch span %.0f\n",
-                        s[0] / wgs, s[1] / wgs, s[2] / wgs, s[3] / wgs, s[4] / wgs, (double)(tmax - tmin));
+                fprintf(stderr, "stamps (mean ticks per workgroup, wave 0): prologue %.0f | K-steps %.0f | wait for staged loads %.0f | "
+                                "LDS store %.0f | barrier %.0f | accumulate total %.0f | epilogue incl. store ack %.0f\n",
+                        s[0] / wgs, s[1] / wgs, s[6] / wgs, s[2] / wgs, s[7] / wgs, s[3] / wgs, s[4] / wgs);
                 b.dbg = nullptr;
                 hipFree(ddbg);
             }
