@@ -124,6 +124,14 @@ int pmp_write_partition_file(const char *path, int frames, int height, int width
 int64_t pmp_format_partition_text(int frames, int height, int width, const uint8_t *hor, const uint8_t *ver,
                                   const uint8_t *qt_u8, const int8_t *dire_i8, char *buf, int64_t cap);
 
+/* ---- binary side channel.  Same content as the text file, laid out as the arrays the patched VTM keeps
+ *      after parsing (Lib/CommonLib/Rom.h:240-248), so a consumer can mmap it instead of 645 k getline+stoi calls per frame:
+ *        char magic[8] = "PMPB1\0\0\0"; int32 frames, height, width, rows (= 16*(H>>6)), cols (= 16*(W>>6)), reserved[3];
+ *        then per frame:  u8 hor[rows][cols] | u8 ver[rows][cols] | u8 qt[rows/2][cols/2] | i8 dire[3][rows][cols]
+ *      (frame matrices, already tiled from the per-block arrays; little-endian; 40-byte header). ---- */
+int pmp_write_partition_binary(const char *path, int frames, int height, int width, const uint8_t *hor, const uint8_t *ver,
+                               const uint8_t *qt_u8, const int8_t *dire_i8);
+
 /* ---- per-kernel-class timing with hipEvents on the launch stream (bench.py roofline leg). -------------- */
 /* mask: bit i enables kernel class i (see pmp_ktime_name); 0 disables.  Resets the accumulators. */
 int pmp_ktime_enable(pmp_ctx *ctx, uint32_t mask);

@@ -542,6 +542,43 @@ int pmp_debug_conv_bench(pmp_ctx *c, int n, int h, int w, int cin, int cout, int
     return rc;
 }
 
+int pmp_write_partition_binary(const char *path, int frames, int H, int W, const uint8_t *hor, const uint8_t *ver,
+                               const uint8_t *qt_u8, const int8_t *dire)
+{
+    if (!path || frames < 0 || H < 0 || W < 0 || !hor || !ver || !qt_u8 || !dire)
+        return set_err(nullptr, PMP_E_INVALID, "pmp_write_partition_binary: bad arguments");
+    const int bh = H / 64, bw = W / 64, R = 16 * bh, C = 16 * bw;
+    FILE *fp = fopen(path, "wb");
+    if (!fp) return set_err(nullptr, PMP_E_IO, std::string("cannot open ") + path);
+    const char magic[8] = {'P', 'M', 'P', 'B', '1', 0, 0, 0};
+    const int32_t hdr[8] = {frames, H, W, R, C, 0, 0, 0};
+    bool ok = fwrite(magic, 1, 8, fp) == 8 && fwrite(hdr, 4, 8, fp) == 8;
+    std::vector<uint8_t> row((size_t)(C > 0 ? C : 1));
+    for (int f = 0; f < frames && ok; ++f) {
+        const int64_t base = (int64_t)f * bh * bw;
+        for (int plane = 0; plane < 2 && ok; ++plane) {
+            const uint8_t *src = plane ? ver : hor;
+            for (int r = 0; r < R && ok; ++r) {
+                for (int cc = 0; cc < C; ++cc) row[cc] = src[(base + (r >> 4) * bw + (cc >> 4)) * 256 + (r & 15) * 16 + (cc & 15)];
+                ok = fwrite(row.data(), 1, (size_t)C, fp) == (size_t)C;
+            }
+        }
+        for (int r = 0; r < R / 2 && ok; ++r) {
+            for (int cc = 0; cc < C / 2; ++cc) row[cc] = qt_u8[(base + (r >> 3) * bw + (cc >> 3)) * 64 + (r & 7) * 8 + (cc & 7)];
+            ok = fwrite(row.data(), 1, (size_t)(C / 2), fp) == (size_t)(C / 2);
+        }
+        for (int k = 0; k < 3 && ok; ++k)
+            for (int r = 0; r < R && ok; ++r) {
+                for (int cc = 0; cc < C; ++cc)
+                    row[cc] = (uint8_t)dire[(base + (r >> 4) * bw + (cc >> 4)) * 768 + k * 256 + (r & 15) * 16 + (cc & 15)];
+                ok = fwrite(row.data(), 1, (size_t)C, fp) == (size_t)C;
+            }
+    }
+    const int cl = fclose(fp);
+    if (!ok || cl != 0) return set_err(nullptr, PMP_E_IO, std::string("short write to ") + path);
+    return PMP_OK;
+}
+
 // ---- timing ------------------------------------------------------------------------------------------------
 int pmp_ktime_classes(void) { return K_NCLASS; }
 

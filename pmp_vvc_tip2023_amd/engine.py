@@ -219,6 +219,31 @@ def write_partition_file(path, frames, height, width, hor, ver, qt_u8, dire_i8):
     _lib.check(lib.pmp_write_partition_file(str(path).encode(), int(frames), int(height), int(width), _ptr(hor), _ptr(ver), _ptr(q8), _ptr(d8)))
 
 
+def write_partition_binary(path, frames, height, width, hor, ver, qt_u8, dire_i8):
+    """Binary side channel of the same data (include/pmp.h): frame matrices as the VTM keeps them."""
+    lib = _lib.load()
+    hor = np.ascontiguousarray(hor, np.uint8); ver = np.ascontiguousarray(ver, np.uint8)
+    q8 = np.ascontiguousarray(qt_u8, np.uint8); d8 = np.ascontiguousarray(dire_i8, np.int8)
+    n = int(frames) * (int(height) // 64) * (int(width) // 64)
+    if hor.size != n * 256 or ver.size != n * 256 or q8.size != n * 64 or d8.size != n * 768:
+        raise ValueError("write_partition_binary: array sizes do not match frames*(H//64)*(W//64) blocks")
+    _lib.check(lib.pmp_write_partition_binary(str(path).encode(), int(frames), int(height), int(width), _ptr(hor), _ptr(ver), _ptr(q8), _ptr(d8)))
+
+
+def read_partition_binary(path):
+    """-> (frames, height, width, hor[F,R,C] u8, ver[F,R,C] u8, qt[F,R/2,C/2] u8, dire[F,3,R,C] i8) via numpy.memmap."""
+    raw = np.memmap(path, dtype=np.uint8, mode="r")
+    if bytes(raw[:8]) != b"PMPB1\0\0\0":
+        raise ValueError("%s: not a PMPB1 file" % path)
+    frames, H, Wd, R, Cc = (int(v) for v in np.frombuffer(raw[8:28].tobytes(), dtype="<i4"))
+    per = 5 * R * Cc + R * Cc // 4
+    body = raw[40:40 + frames * per].reshape(frames, per)
+    hor = body[:, :R * Cc].reshape(frames, R, Cc); ver = body[:, R * Cc:2 * R * Cc].reshape(frames, R, Cc)
+    qt = body[:, 2 * R * Cc:2 * R * Cc + R * Cc // 4].reshape(frames, R // 2, Cc // 2)
+    dire = body[:, 2 * R * Cc + R * Cc // 4:].reshape(frames, 3, R, Cc).view(np.int8)
+    return frames, H, Wd, hor, ver, qt, dire
+
+
 def format_partition_text(frames, height, width, hor, ver, qt_u8, dire_i8):
     lib = _lib.load()
     hor = np.ascontiguousarray(hor, np.uint8); ver = np.ascontiguousarray(ver, np.uint8)

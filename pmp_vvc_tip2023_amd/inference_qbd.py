@@ -105,6 +105,7 @@ def build_parser():
     p.add_argument("--qps", default="22,27,32,37")
     p.add_argument("--comps", default="Luma,Chroma")
     p.add_argument("--device", default=None, type=int, help="GPU index (default: LOCAL_RANK)")
+    p.add_argument("--binary", action="store_true", help="also write <name>_PartitionMat.pmpb (binary side channel, include/pmp.h)")
     return p
 
 
@@ -176,6 +177,8 @@ def inference_VVC_seqs(args):
                     save_path = os.path.join(save_dir, "%s_%s_QP%d_PartitionMat.txt" % (stem, comp, qp))
                     print("Save:", save_path, flush=True)
                     E.write_partition_file(save_path, sub_numfrm, height, width, h, vv, q, d)
+                    if args.binary:
+                        E.write_partition_binary(save_path[:-4] + ".pmpb", sub_numfrm, height, width, h, vv, q, d)
                 seqs_post_time[si, qi, comp_id] = time.time() - t0
 
     if rank == 0:  # Time_Sta log, Inference_QBD.py:243-253 (net column = inference + GPU post-processing here)

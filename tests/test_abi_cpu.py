@@ -82,3 +82,18 @@ def test_writer_errors(lib, tmp_path):
     # empty sequence: zero frames -> empty file
     engine.write_partition_file(str(tmp_path / "e"), 0, 64, 64, z[:0], z[:0], np.zeros((0, 8, 8), np.uint8), np.zeros((0, 3, 16, 16), np.int8))
     assert os.path.getsize(str(tmp_path / "e")) == 0
+
+
+@pytest.mark.parametrize("comp", ["Luma", "Chroma"])
+def test_binary_side_channel_equals_text(lib, comp, tmp_path, oracle_lib):
+    """N2: the binary file holds exactly the numbers of the reference's text file, in the same order."""
+    g = golden("g5_seq_%s.npz" % comp)
+    F, W, H = int(g["F"]), int(g["W"]), int(g["H"])
+    hor, ver, q, dout = oracle_lib.seq_post_process(g["qt"], g["bt"], g["dire"], comp, F, W, H, None)
+    pb = str(tmp_path / "p.pmpb")
+    engine.write_partition_binary(pb, F, H, W, hor, ver, q.astype(np.uint8), dout)
+    f, h, w, bh, bv, bq, bd = engine.read_partition_binary(pb)
+    assert (f, h, w) == (F, H, W)
+    th, tv, tq, td = engine.read_partition_file(golden_path("g5_partitionmat_%s.txt" % comp), F, H, W)
+    assert np.array_equal(bh, th) and np.array_equal(bv, tv) and np.array_equal(bq, tq) and np.array_equal(bd, td)
+    assert os.path.getsize(pb) == 40 + F * (5 * 16 * 32 + 8 * 16)
