@@ -2,6 +2,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <memory>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -397,37 +399,84 @@ int pmp_cut_blocks(pmp_ctx *c, const void *y, const void *u, const void *v, int 
 }
 
 // ---- PartitionMat text (Map2Partition.py:385-412) ---------------------------------------------------------
+// Emission is the host-side hot spot of the path: 645 k lines per 1080p frame and file.  Values are in
+// {-1, 0, 1, 2, 3}, so a line is "d\n" or "-1\n": 16 values of one block row are contiguous in the per-block arrays and are
+// expanded with one 16-bit store each (an unconditional '-' is written first and kept only for negative values).
+static inline char *emit_u8_row(char *p, const uint8_t *v, int count)
+{
+    unsigned m = 0;
+    for (int i = 0; i < count; ++i) m |= v[i];
+    if (m < 8) {   // every value is a single digit: fixed 2 bytes per value, no branches
+        for (int i = 0; i < count; ++i) { p[2 * i] = (char)('0' + v[i]); p[2 * i + 1] = '\n'; }
+        return p + 2 * count;
+    }
+    for (int i = 0; i < count; ++i) {
+        const unsigned d = v[i];
+        if (d < 10) { p[0] = (char)('0' + d); p[1] = '\n'; p += 2; }
+        else { p += snprintf(p, 8, "%u\n", d); }   // never produced by the path; kept for arbitrary caller data
+    }
+    return p;
+}
+
+static inline char *emit_i8_row(char *p, const int8_t *v, int count)
+{
+    for (int i = 0; i < count; ++i) {
+        const int d = v[i];
+        p[0] = '-';
+        p += d < 0;
+        const int a = d < 0 ? -d : d;
+        if (a < 10) { p[0] = (char)('0' + a); p[1] = '\n'; p += 2; }
+        else { p += snprintf(p, 8, "%d\n", a); }
+    }
+    return p;
+}
+
 int64_t pmp_format_partition_text(int frames, int H, int W, const uint8_t *hor, const uint8_t *ver, const uint8_t *qt_u8,
                                   const int8_t *dire, char *buf, int64_t cap)
 {
     if (frames < 0 || H < 0 || W < 0 || !hor || !ver || !qt_u8 || !dire) return set_err(nullptr, PMP_E_INVALID, "pmp_format_partition_text: bad arguments");
-    const int bh = H / 64, bw = W / 64, R = 16 * bh, C = 16 * bw;
-    int64_t pos = 0;
-    auto put = [&](int v) {  // values are in {-1, 0..3}: "d\n" or "-d\n"
-        if (v < 0) { if (buf && pos < cap) buf[pos] = '-'; ++pos; v = -v; }
-        if (v >= 100) { if (buf && pos < cap) buf[pos] = (char)('0' + v / 100); ++pos; }
-        if (v >= 10) { if (buf && pos < cap) buf[pos] = (char)('0' + (v / 10) % 10); ++pos; }
-        if (buf && pos < cap) buf[pos] = (char)('0' + v % 10);
-        ++pos;
-        if (buf && pos < cap) buf[pos] = '\n';
-        ++pos;
-    };
+    const int bh = H / 64, bw = W / 64, R = 16 * bh;
+    const int64_t nblk = (int64_t)frames * bh * bw;
+    if (!buf) {   // exact size: 2 bytes per value, +1 per negative direction, +digits beyond one for values >= 10
+        int64_t need = nblk * (256 + 256 + 64 + 768) * 2, neg = 0;
+        int amax = 0;
+        for (int64_t i = 0; i < nblk * 768; ++i) { neg += dire[i] < 0; const int a = dire[i] < 0 ? -dire[i] : dire[i]; amax = a > amax ? a : amax; }
+        unsigned umax = 0;
+        for (int64_t i = 0; i < nblk * 256; ++i) { umax = hor[i] > umax ? hor[i] : umax; umax = ver[i] > umax ? ver[i] : umax; }
+        for (int64_t i = 0; i < nblk * 64; ++i) umax = qt_u8[i] > umax ? qt_u8[i] : umax;
+        need += neg;
+        if (amax >= 10 || umax >= 10) {   // never on the path's own data; exact for arbitrary caller data
+            for (int64_t i = 0; i < nblk * 768; ++i) { const int a = dire[i] < 0 ? -dire[i] : dire[i]; need += (a >= 10) + (a >= 100); }
+            for (int64_t i = 0; i < nblk * 256; ++i) need += (hor[i] >= 10) + (hor[i] >= 100) + (ver[i] >= 10) + (ver[i] >= 100);
+            for (int64_t i = 0; i < nblk * 64; ++i) need += (qt_u8[i] >= 10) + (qt_u8[i] >= 100);
+        }
+        return need;
+    }
+    // the caller sized the buffer with the call above; a row of 16 values needs at most 16 * 5 bytes
+    char *p = buf, *end = buf + cap;
     for (int f = 0; f < frames; ++f) {
         const int64_t base = (int64_t)f * bh * bw;
         for (int plane = 0; plane < 2; ++plane) {
             const uint8_t *src = plane ? ver : hor;
             for (int r = 0; r < R; ++r)
-                for (int cc = 0; cc < C; ++cc) put(src[(base + (r >> 4) * bw + (cc >> 4)) * 256 + (r & 15) * 16 + (cc & 15)]);
+                for (int bx = 0; bx < bw; ++bx) {
+                    if (end - p < 80) return set_err(nullptr, PMP_E_INVALID, "pmp_format_partition_text: buffer too small");
+                    p = emit_u8_row(p, src + (base + (int64_t)(r >> 4) * bw + bx) * 256 + (r & 15) * 16, 16);
+                }
         }
         for (int r = 0; r < R / 2; ++r)
-            for (int cc = 0; cc < C / 2; ++cc) put(qt_u8[(base + (r >> 3) * bw + (cc >> 3)) * 64 + (r & 7) * 8 + (cc & 7)]);
+            for (int bx = 0; bx < bw; ++bx) {
+                if (end - p < 40) return set_err(nullptr, PMP_E_INVALID, "pmp_format_partition_text: buffer too small");
+                p = emit_u8_row(p, qt_u8 + (base + (int64_t)(r >> 3) * bw + bx) * 64 + (r & 7) * 8, 8);
+            }
         for (int k = 0; k < 3; ++k)
             for (int r = 0; r < R; ++r)
-                for (int cc = 0; cc < C; ++cc)
-                    put(dire[(base + (r >> 4) * bw + (cc >> 4)) * 768 + k * 256 + (r & 15) * 16 + (cc & 15)]);
+                for (int bx = 0; bx < bw; ++bx) {
+                    if (end - p < 80) return set_err(nullptr, PMP_E_INVALID, "pmp_format_partition_text: buffer too small");
+                    p = emit_i8_row(p, dire + (base + (int64_t)(r >> 4) * bw + bx) * 768 + k * 256 + (r & 15) * 16, 16);
+                }
     }
-    if (buf && pos > cap) return set_err(nullptr, PMP_E_INVALID, "pmp_format_partition_text: buffer too small");
-    return pos;
+    return p - buf;
 }
 
 int pmp_write_partition_file(const char *path, int frames, int H, int W, const uint8_t *hor, const uint8_t *ver,
@@ -436,12 +485,13 @@ int pmp_write_partition_file(const char *path, int frames, int H, int W, const u
     if (!path) return set_err(nullptr, PMP_E_INVALID, "pmp_write_partition_file: null path");
     const int64_t need = pmp_format_partition_text(frames, H, W, hor, ver, qt_u8, dire, nullptr, 0);
     if (need < 0) return (int)need;
-    std::string buf((size_t)need, '\0');
-    if (need && pmp_format_partition_text(frames, H, W, hor, ver, qt_u8, dire, &buf[0], need) != need)
+    std::unique_ptr<char[]> buf(new (std::nothrow) char[(size_t)need + 96]);   // slack: room for one more row, see pmp.h
+    if (!buf) return set_err(nullptr, PMP_E_NOMEM, "pmp_write_partition_file: out of host memory");
+    if (need && pmp_format_partition_text(frames, H, W, hor, ver, qt_u8, dire, buf.get(), need + 96) != need)
         return set_err(nullptr, PMP_E_INVALID, "pmp_write_partition_file: formatting failed");
     FILE *fp = fopen(path, "wb");
     if (!fp) return set_err(nullptr, PMP_E_IO, std::string("cannot open ") + path);
-    const size_t wr = need ? fwrite(buf.data(), 1, (size_t)need, fp) : 0;
+    const size_t wr = need ? fwrite(buf.get(), 1, (size_t)need, fp) : 0;
     const int cl = fclose(fp);
     if (wr != (size_t)need || cl != 0) return set_err(nullptr, PMP_E_IO, std::string("short write to ") + path);
     return PMP_OK;

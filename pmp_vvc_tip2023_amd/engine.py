@@ -249,8 +249,9 @@ def format_partition_text(frames, height, width, hor, ver, qt_u8, dire_i8):
     hor = np.ascontiguousarray(hor, np.uint8); ver = np.ascontiguousarray(ver, np.uint8)
     q8 = np.ascontiguousarray(qt_u8, np.uint8); d8 = np.ascontiguousarray(dire_i8, np.int8)
     need = _lib.check(lib.pmp_format_partition_text(int(frames), int(height), int(width), _ptr(hor), _ptr(ver), _ptr(q8), _ptr(d8), None, 0))
-    buf = C.create_string_buffer(int(need) if need else 1)
-    _lib.check(lib.pmp_format_partition_text(int(frames), int(height), int(width), _ptr(hor), _ptr(ver), _ptr(q8), _ptr(d8), buf, need))
+    buf = C.create_string_buffer(int(need) + 96)      # the formatter wants room for one more row while it writes
+    got = _lib.check(lib.pmp_format_partition_text(int(frames), int(height), int(width), _ptr(hor), _ptr(ver), _ptr(q8), _ptr(d8), buf, need + 96))
+    assert got == need
     return buf.raw[:need]
 
 

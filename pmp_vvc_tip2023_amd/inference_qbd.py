@@ -22,6 +22,7 @@ import argparse
 import os
 import sys
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -109,6 +110,13 @@ def build_parser():
     return p
 
 
+def _emit(rec, save_path, frames, height, width, binary):
+    h, v, q, d = parallel.unpack_records(rec)
+    E.write_partition_file(save_path, frames, height, width, h, v, q, d)
+    if binary:
+        E.write_partition_binary(save_path[:-4] + ".pmpb", frames, height, width, h, v, q, d)
+
+
 def _resolve(path, base):
     return path if os.path.isabs(path) or os.path.exists(path) else os.path.join(base, path)
 
@@ -139,6 +147,8 @@ def inference_VVC_seqs(args):
     seqs_net_time = np.zeros((max(nseq, 1), 4, 2))
     seqs_post_time = np.zeros((max(nseq, 1), 4, 2))
 
+    writers = ThreadPoolExecutor(max_workers=4) if rank == 0 else None
+    pending = []
     for comp in comps:  # weights once per (comp, qp), not once per sequence
         for qp in qps:
             eng.load(comp, qp)
@@ -173,14 +183,18 @@ def inference_VVC_seqs(args):
                 t0 = time.time()
                 rec = parallel.gather_records(parallel.pack_records(hor, ver, q8, d8), n_total, device)
                 if rank == 0:
-                    h, vv, q, d = parallel.unpack_records(rec)
+                    # text emission (645 k lines per 1080p frame and file) runs on writer threads - the C writer releases
+                    # the GIL - so it overlaps the next (component, QP) pass instead of serialising rank 0
                     save_path = os.path.join(save_dir, "%s_%s_QP%d_PartitionMat.txt" % (stem, comp, qp))
                     print("Save:", save_path, flush=True)
-                    E.write_partition_file(save_path, sub_numfrm, height, width, h, vv, q, d)
-                    if args.binary:
-                        E.write_partition_binary(save_path[:-4] + ".pmpb", sub_numfrm, height, width, h, vv, q, d)
+                    pending.append(writers.submit(_emit, rec, save_path, sub_numfrm, height, width, args.binary))
                 seqs_post_time[si, qi, comp_id] = time.time() - t0
 
+        for fut in pending:   # bound memory: a sequence's files are on disk before the next one starts
+            fut.result()
+        pending = []
+    if writers:
+        writers.shutdown(wait=True)
     if rank == 0:  # Time_Sta log, Inference_QBD.py:243-253 (net column = inference + GPU post-processing here)
         sta = os.path.join(args.outDir, args.jobID, "Time_Sta_%d_%d.txt" % (args.startSeqID, args.startSeqID + args.seqNum))
         with open(sta, "w") as fp:
