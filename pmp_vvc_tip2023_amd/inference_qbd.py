@@ -125,6 +125,9 @@ def inference_VVC_seqs(args):
     """Inference_QBD.py:151-255."""
     rank, world, local = parallel.env_world()
     dev_id = args.device if args.device is not None else local
+    if args.device is None and world > 1:
+        import torch
+        dev_id = local % max(torch.cuda.device_count(), 1)   # several ranks may share a GPU in smoke tests (gloo)
     eng = E.Engine(dev_id, weight_dir=args.modelDir if os.path.isdir(args.modelDir) else None)
     eng.set_chunk(max(1, args.batchSize))
     device = None

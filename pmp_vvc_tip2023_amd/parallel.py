@@ -58,7 +58,7 @@ def init_process_group(device=None):
         import torch.distributed as dist
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            backend = "nccl" if (device is not None and torch.cuda.is_available()) else "gloo"
+            backend = os.environ.get("PMP_DIST_BACKEND") or ("nccl" if (device is not None and torch.cuda.is_available()) else "gloo")
             kw = {"device_id": device} if backend == "nccl" else {}
             dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world, local

@@ -310,3 +310,38 @@ def test_end_to_end_flags_vs_reference_logits(eng, g1, oracle_lib):
             total += hor.size + ver.size + q8.size + d8.size
     assert total == 8 * 8 * 1344
     assert mism == 0, "%d of %d emitted values differ from the reference-logit path" % (mism, total)
+
+
+def test_driver_two_ranks_equal_one_rank(tmp_path):
+    """The sharded driver (2 processes, blocks split between them, gather to rank 0) writes the same files as a single
+    process.  Both ranks share the one GPU of the test box, so the collective runs over gloo here; on a multi-GPU node the
+    same code path uses RCCL."""
+    import os, socket, subprocess, sys
+    from pmp_vvc_tip2023_amd import inference_qbd as D, synth
+    inp = tmp_path / "in"; cfg = tmp_path / "cfg"
+    inp.mkdir(); cfg.mkdir()
+    w, h, fr = 320, 192, 3                                   # 5 x 3 blocks per frame, 3 frames -> 45 blocks, odd split
+    with open(inp / "table.txt", "w") as f:
+        f.write("SeqC,SeqC_320x192_30.yuv,%d,%d,%d,30\n#end!!!!\n" % (w, h, fr))
+    y, u, v = synth.recipe_r_frames(fr, h, w, 91)
+    with open(inp / "SeqC_320x192_30.yuv", "wb") as f:
+        for i in range(fr):
+            f.write(y[i].tobytes()); f.write(u[i].tobytes()); f.write(v[i].tobytes())
+    with open(cfg / "SeqC.cfg", "w") as f:
+        f.write("InputFile : SeqC_320x192_30.yuv\nInputBitDepth : 8\n")
+    common = ["--inputDir", str(inp), "--seqTable", "table.txt", "--cfgDir", str(cfg), "--ssRatio", "1", "--seqNum", "1", "--qps", "22,32"]
+    D.main(["--jobID", "one", "--outDir", str(tmp_path / "o1")] + common)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", PMP_DIST_BACKEND="gloo", PYTHONPATH=root)
+    procs = [subprocess.Popen([sys.executable, "-m", "pmp_vvc_tip2023_amd.inference_qbd", "--jobID", "two", "--outDir", str(tmp_path / "o2")] + common,
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    logs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    d1 = tmp_path / "o1" / "one" / "PartitionMat"; d2 = tmp_path / "o2" / "two" / "PartitionMat"
+    names = sorted(os.listdir(d1))
+    assert len(names) == 4 and names == sorted(os.listdir(d2))
+    for nme in names:
+        assert open(d1 / nme, "rb").read() == open(d2 / nme, "rb").read(), nme
