@@ -224,7 +224,13 @@ __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__
         if (ABL & 128) { const unsigned long long t = stamp_now(); t_k += t - tmark; tmark = t; }
         // the partner buffer is only overwritten here, after the last K-step that may read the previous group from it
         if ((ABL & 128) && more) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long t = stamp_now(); t_w += t - tmark; tmark = t; }
-        if (more && !(ABL & 1)) x6_stage_store<KH, KW>(plan, lds + ((cb + 1) & 1) * G::PIECES, r);
+        if (more && !(ABL & 1)) {
+            if (ABL & 256) {   // timing-only: keep the loads alive, skip the LDS stores
+#pragma unroll
+                for (int k = 0; k < G::NLD; ++k) asm volatile("" ::"v"(r[k]));
+            } else
+                x6_stage_store<KH, KW>(plan, lds + ((cb + 1) & 1) * G::PIECES, r);
+        }
         if (ABL & 128) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t = stamp_now(); t_s += t - tmark; tmark = t; }
         if (!(ABL & 16)) __syncthreads();
         if (ABL & 128) { const unsigned long long t = stamp_now(); t_b += t - tmark; tmark = t; }
@@ -338,6 +344,7 @@ static hipError_t launch_x6(hipStream_t s, const ConvX6Args &a)
             case 32: hipLaunchKernelGGL((conv_x6_kernel<3, 3, 4, 32>), dim3(grid), dim3(256), 0, s, a); break;
             case 40: hipLaunchKernelGGL((conv_x6_kernel<3, 3, 4, 40>), dim3(grid), dim3(256), 0, s, a); break;
             case 128: hipLaunchKernelGGL((conv_x6_kernel<3, 3, 4, 128>), dim3(grid), dim3(256), 0, s, a); break;
+            case 200: hipLaunchKernelGGL((conv_x6_kernel<3, 3, 4, 256>), dim3(grid), dim3(256), 0, s, a); break;
             default: hipLaunchKernelGGL((conv_x6_kernel<KH, KW, 4>), dim3(grid), dim3(256), 0, s, a); break;
             }
         } else

@@ -7,7 +7,7 @@ shapes = [(256, 64, 64, 64, 64, 3), (256, 64, 64, 64, 64, 5), (256, 64, 64, 32, 
 abl = [0]
 if len(sys.argv) > 1 and sys.argv[1] == "ablate":
     shapes = [(256, 64, 64, 64, 64, 3)]
-    abl = [0, 128]      # bits: 1 staging, 2 weight loads, 4 x reads, 8 epilogue, 16 barrier
+    abl = [0, 1, 2, 4, 8, 16, 32, 200, 128]      # bits: 1 staging, 2 weight loads, 4 x reads, 8 epilogue, 16 barrier, 32 staging from L2-resident addresses, 200 = LDS stores only, 128 = stamps
 elif len(sys.argv) > 1:
     shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
 for ab in abl:
