@@ -33,14 +33,6 @@ __device__ __forceinline__ unsigned long long stamp_now()
     return t;
 }
 
-template <int KH, int KW>
-struct GeoX {
-    static constexpr int TH = 16 + KH - 1, TW = 16 + KW - 1, TAPS = KH * KW, NKS = (TAPS + 1) / 2;
-    static constexpr int PLANE = TH * TW * 2;            // 16-B pieces per split plane (32 B per pixel)
-    static constexpr int PIECES = 3 * PLANE;             // per buffer
-    static constexpr int NLD = (PIECES + 255) / 256;
-};
-
 // Per-lane staging plan, computed ONCE per workgroup: element offset (inside one 16-channel group, split plane
 // included) of each 16-B piece this thread copies, and a validity mask for the zero padding.  The per-group work is then
 // one add per piece; recomputing the div/mod chain per group cost ~80 VALU issue slots per K-step, which matters when a
@@ -123,8 +115,9 @@ __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__
     // unconditional so hipcc's s_waitcnt vmcnt(N) are exact counts; scheduling fences pin the phase order.
     // Tap pairing.  A K-step covers 16 channels x 2 taps.  With an odd tap count the last tap has no partner inside its
     // channel group; when the number of groups is even ("paired" packing, see pack_x6) the last tap of an EVEN group is
-    // deferred and paired with the last tap of the following ODD group - both halo tiles are resident then, the even one
-    // in the other LDS buffer - so no MFMA work is spent on zero padding (3x3: 9 K-steps per two groups instead of 10).
+    // deferred and paired with the last tap of the following ODD group, as that group's first K-step - both halo tiles
+    // are resident then, the even one in the other LDS buffer (it is overwritten only at the end of the odd group) - so
+    // no MFMA work is spent on zero padding (3x3: 9 K-steps per two groups instead of 10).
     //   mode 0 (plain): NKS = ceil(T/2) per group, last pair padded with zero weights
     //   mode 1 (even group of a pair): (T-1)/2 K-steps;  mode 2 (odd group): (T-1)/2 + 1 K-steps
     const bool paired = (CB & 1) == 0 && (G::TAPS & 1);
@@ -140,7 +133,7 @@ __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__
     auto group = [&](auto mode_tag, int cb) {
         constexpr int MODE = decltype(mode_tag)::value;
         constexpr int NK = MODE == 0 ? G::NKS : (MODE == 1 ? (G::TAPS - 1) / 2 : (G::TAPS - 1) / 2 + 1);
-        constexpr int PER = NK > 0 ? (G::NLD + NK - 1) / NK : G::NLD;   // staging loads issued per K-step
+        constexpr int PER = (G::NLD + (NK > 0 ? NK : 1) - 1) / (NK > 0 ? NK : 1);   // staging loads issued per K-step
         const bool more = cb + 1 < CB;
         const unsigned short *nxt_grp = ((ABL & 32) ? x : grp0) + (size_t)min(cb + 1, CB - 1) * grp_sz;   // clamped: loads stay unconditional
         const char *buf = reinterpret_cast<const char *>(lds + (cb & 1) * G::PIECES);
@@ -150,7 +143,10 @@ __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__
             int tA = 2 * ks, tB = 2 * ks + 1;
             bool prevA = false;
             if (MODE == 0 && tB >= G::TAPS) tB = tA;
-            if (MODE == 2 && ks == NK - 1) { tA = tB = G::TAPS - 1; prevA = true; }
+            if (MODE == 2) {   // first K-step of an odd group: the deferred tap of the even group + this group's last tap
+                if (ks == 0) { tA = tB = G::TAPS - 1; prevA = true; }
+                else { tA = 2 * (ks - 1); tB = tA + 1; }
+            }
             const int oA = ((tA / KW) * G::TW + tA % KW) * 32, oB = ((tB / KW) * G::TW + tB % KW) * 32;
             return (tapsel ? buf + oB : (prevA ? prv : buf) + oA) + pb;
         };

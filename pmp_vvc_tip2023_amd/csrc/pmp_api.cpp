@@ -1,6 +1,7 @@
 // pmp_api.cpp — the C ABI declared in include/pmp.h.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -171,6 +172,7 @@ int pmp_create(int device_id, pmp_ctx **out)
     if ((e = hipSetDevice(device_id)) != hipSuccess) return hip_fail(nullptr, e, "hipSetDevice");
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return hip_fail(nullptr, e, "hipGetDeviceProperties");
+    if (const char *v = getenv("PMP_CONV_VARIANT")) g_conv_variant = atoi(v);   // debug knob, see pmp_debug_set_conv_variant
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
         return set_err(nullptr, PMP_E_NODEVICE, std::string("pmp_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName);
     pmp_ctx *c = new (std::nothrow) pmp_ctx();

@@ -39,6 +39,15 @@ __device__ __forceinline__ void store_split4(unsigned short *p, size_t plane_str
     *reinterpret_cast<bf16x4 *>(p + 2 * plane_stride) = c;
 }
 
+// halo-tile geometry of the split-3 MFMA kernels (conv_bf16x6.hip, conv_x6_ws.hip): 16x16 output pixels per workgroup
+template <int KH, int KW>
+struct GeoX {
+    static constexpr int TH = 16 + KH - 1, TW = 16 + KW - 1, TAPS = KH * KW, NKS = (TAPS + 1) / 2;
+    static constexpr int PLANE = TH * TW * 2;            // 16-B pieces per split plane (32 B per pixel)
+    static constexpr int PIECES = 3 * PLANE;             // per buffer
+    static constexpr int NLD = (PIECES + 255) / 256;
+};
+
 // fp32 blocked tensor or split-3 planes behind one store call (elements, not bytes, index both)
 struct ActOut {
     float *f32;

@@ -105,9 +105,9 @@ std::vector<unsigned short> pack_x6(const float *w, int cout, int cin, int kh, i
     struct Half { int cb, tap; };
     std::vector<std::pair<Half, Half>> steps;
     if (paired) {
-        for (int cb = 0; cb < CB; ++cb) {
-            for (int ks = 0; ks < (taps - 1) / 2; ++ks) steps.push_back({{cb, 2 * ks}, {cb, 2 * ks + 1}});
+        for (int cb = 0; cb < CB; ++cb) {   // the cross-group pair is the FIRST K-step of the odd group
             if (cb & 1) steps.push_back({{cb - 1, taps - 1}, {cb, taps - 1}});
+            for (int ks = 0; ks < (taps - 1) / 2; ++ks) steps.push_back({{cb, 2 * ks}, {cb, 2 * ks + 1}});
         }
     } else {
         for (int cb = 0; cb < CB; ++cb)

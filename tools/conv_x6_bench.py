@@ -13,7 +13,7 @@ elif len(sys.argv) > 1:
 for ab in abl:
   eng.lib.pmp_debug_set_conv_variant(10 + ab if ab else 2)
   for (n, h, w, ci, co, k) in shapes:
-    if ab: print("ablation bits", ab, end=": ")
+    if ab: print("ablation bits %d" % ab, end=": ")
     a, b, d, r = C.c_double(), C.c_double(), C.c_double(), C.c_double()
     eng._ck(eng.lib.pmp_debug_conv_bench(eng.h, n, h, w, ci, co, k, 10, C.byref(a), C.byref(b), C.byref(d), C.byref(r)))
     fl = 2.0 * n * h * w * co * ci * k * k
