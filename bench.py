@@ -25,10 +25,14 @@ import numpy as np
 import torch
 
 FLOP_PER_BLOCK = {"Luma": 6.991e9, "Chroma": 2.300e9}      # conv MACs x 2, QT + MTT
-# Peak of the datapath actually used: the exact-fp32 MFMA, or the dense bf16 MFMA peak divided by the six
-# bf16 products the 3-term split spends per fp32 product (MI355X_MICROARCH.md: 157.3 TF fp32 matrix, ~2.5 PF bf16 dense).
-PEAK_TFLOPS = {"fp32": 157.3, "bf16x6": 2500.0 / 6.0}
-PEAK_NOTE = {"fp32": "v_mfma_f32_16x16x4_f32 peak 157.3 TFLOP/s (register-resident loop on this pool: 154.7)",
+# Peak of the datapath actually used: the exact-fp32 MFMA, or the dense 16-bit MFMA peak divided by the
+# number of 16-bit products the split spends per fp32-accurate product: 3 (two fp16 terms) or 6 (three bf16 terms)
+# (MI355X_MICROARCH.md: 157.3 TF fp32 matrix, ~2.5 PF bf16/fp16 dense).
+PEAK_TFLOPS = {"fp32": 157.3, "bf16x6": 2500.0 / 6.0, "f16x3": 2500.0 / 3.0}
+PEAK_NOTE = {"f16x3": "fp16 dense MFMA peak 2500 TFLOP/s / 3 products per fp32-accurate product = 833.3 "
+                      "(a register-resident 16-bit MFMA loop on this pool sustains 1925 TFLOP/s = 641.7 per fp32-accurate product, "
+                      "profiles/r01_mfma_peak_microbench.txt)",
+             "fp32": "v_mfma_f32_16x16x4_f32 peak 157.3 TFLOP/s (register-resident loop on this pool: 154.7)",
              "bf16x6": "bf16 dense MFMA peak 2500 TFLOP/s / 6 products per fp32-accurate product = 416.7 "
                        "(register-resident bf16 loop on this pool sustains 1925 TFLOP/s at 1.97 GHz = 320.9 per fp32 product, "
                        "profiles/r01_mfma_peak_microbench.txt)"}
@@ -87,8 +91,9 @@ def main():
     ap.add_argument("--qp", type=int, default=22)
     ap.add_argument("--chunk", type=int, default=0, help="blocks per pass inside the library (0 = library default)")
     ap.add_argument("--cpu-sample", type=int, default=512, help="blocks for the CPU baseline (0 = skip)")
-    ap.add_argument("--precision", default="bf16x6", choices=["bf16x6", "fp32"],
-                    help="conv datapath: 3-term bf16 split (6 MFMA products, fp32-equivalent) or exact fp32 MFMA")
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "bf16x6", "fp32"],
+                    help="conv datapath: 2-term fp16 split (3 MFMA products) or 3-term bf16 split (6 products), both "
+                         "fp32-equivalent, or exact fp32 MFMA")
     ap.add_argument("--breakdown", action="store_true", help="extra pass with every kernel class timed (stderr)")
     args = ap.parse_args()
 
@@ -212,13 +217,15 @@ def main():
             "metric": "CTUs/sec (luma QT+MTT inference+post-proc)", "value": round(blocks_per_s / 4.0, 2), "unit": "CTU/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16x6", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else args.precision, "data": "synthetic",
             "config": {"workload": "%s QT+MTT nets QP%d, batch=%d synthetic 64x64 blocks (68x68 u8 inputs) per GPU, "
                                    "device-resident infer+Map2Partition; CTU = 128x128 = 4 blocks" % (args.comp, args.qp, n),
                        "blocks_per_gpu": n, "global_blocks": n * n_gpus, "parallelism": "dp%d (blocks sharded, gather of split flags to rank 0)" % n_gpus,
                        "weights": "QT real (reference trained_models), MTT synthetic seed=qp",
-                       "datapath": "fp32 MFMA" if args.precision == "fp32" else
-                                   "bf16 MFMA, every fp32 operand split into 3 bf16 terms, 6 products, fp32 accumulate (fp32-equivalent logits)"},
+                       "datapath": {"fp32": "fp32 MFMA",
+                                    "bf16x6": "bf16 MFMA, every fp32 operand split into 3 bf16 terms, 6 products, fp32 accumulate (fp32-equivalent logits)",
+                                    "f16x3": "fp16 MFMA, every fp32 operand split into 2 fp16 terms (weights pre-scaled by 2^k), 3 products, "
+                                             "fp32 accumulate (fp32-equivalent logits)"}[args.precision]},
             "blocks_per_s": round(blocks_per_s, 1),
             "net_tflops": round(blocks_per_s * FLOP_PER_BLOCK[args.comp] / 1e12, 2),
             "roofline": roof,

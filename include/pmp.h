@@ -72,11 +72,14 @@ int pmp_synchronize(pmp_ctx *ctx);
 /* Blocks processed per pass (activation workspace is sized for it); n > chunk is looped.  1..4096, default 1024. */
 int pmp_set_chunk(pmp_ctx *ctx, int blocks);
 
-/* Convolution datapath.  Both are fp32-accurate; results differ in the last bits only.
+/* Convolution datapath.  All three are fp32-accurate; results differ in the last bits only.
  *   PMP_PRECISION_F32    v_mfma_f32_16x16x4_f32, exact fp32 fmaf chain
- *   PMP_PRECISION_BF16X6 (default) every fp32 operand carried as 3 bf16 terms, 6 bf16 MFMA products, fp32 accumulate */
+ *   PMP_PRECISION_BF16X6 every fp32 operand carried as 3 bf16 terms, 6 bf16 MFMA products, fp32 accumulate
+ *   PMP_PRECISION_F16X3  (default) every fp32 operand carried as 2 fp16 terms (weights pre-scaled by a power of two),
+ *                        3 fp16 MFMA products, fp32 accumulate; activations beyond +-65504 saturate */
 #define PMP_PRECISION_F32 0
 #define PMP_PRECISION_BF16X6 1
+#define PMP_PRECISION_F16X3 2
 int pmp_set_precision(pmp_ctx *ctx, int mode);
 int pmp_get_precision(const pmp_ctx *ctx);
 

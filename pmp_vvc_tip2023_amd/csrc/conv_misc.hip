@@ -21,7 +21,7 @@ __device__ __forceinline__ size_t act_idx(int n, int c, int y, int x, int CB, in
 //   chroma MSBD : 4 planes 36x36, conv 5x5 -> 16, 3x5 -> 8, 5x3 -> 8  (Model_QBD.py:228-233)
 // Right/bottom zero padding of 4 (2) is common to all convs: the (5,9) conv pads right only but never reads below
 // row y+4 <= 67, the (9,5) conv pads bottom only but never reads right of x+4 <= 67.
-template <int KH, int KW, int CIN, int PS, int ROWS, bool SPLIT>
+template <int KH, int KW, int CIN, int PS, int ROWS, int FMT>
 __device__ __forceinline__ void stem_conv(const float *__restrict__ planes, const float *__restrict__ w,
                                           const float *__restrict__ bias, int cout, int x, int y0, int OUT,
                                           const ActOut &out, size_t out_n, int ch_off)
@@ -63,13 +63,13 @@ __device__ __forceinline__ void stem_conv(const float *__restrict__ planes, cons
             const size_t o = out_n + (((size_t)(c >> 4) * OUT + (y0 + r)) * OUT + x) * 16 + (c & 15);
             f32x4 v0 = {fmaxf(acc[r][0], 0.f), fmaxf(acc[r][1], 0.f), fmaxf(acc[r][2], 0.f), fmaxf(acc[r][3], 0.f)};
             f32x4 v1 = {fmaxf(acc[r][4], 0.f), fmaxf(acc[r][5], 0.f), fmaxf(acc[r][6], 0.f), fmaxf(acc[r][7], 0.f)};
-            if (SPLIT) { store_split4(out.s3 + o, out.stride, v0); store_split4(out.s3 + o + 4, out.stride, v1); }
+            if (FMT != FMT_F32) { store_fmt4<FMT>(out.s3 + o, out.stride, v0); store_fmt4<FMT>(out.s3 + o + 4, out.stride, v1); }
             else { *reinterpret_cast<f32x4 *>(out.f32 + o) = v0; *reinterpret_cast<f32x4 *>(out.f32 + o + 4) = v1; }
         }
     }
 }
 
-template <bool LUMA, bool MSBD, bool SPLIT>
+template <bool LUMA, bool MSBD, int FMT>
 __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
 {
     constexpr int S = LUMA ? 68 : 34, P = LUMA ? 4 : 2, PS = S + P, OUT = S - P;  // 72/36 planes, 64/32 outputs
@@ -113,18 +113,18 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
     __syncthreads();
 
     const size_t out_n = (size_t)n * 2 * OUT * OUT * 16;
-    const ActOut out{a.out, a.out_s3, a.s3_stride};
+    const ActOut out{a.out, a.out_s3, a.s3_stride, FMT};
     constexpr int COLS_PER_WG = 256 / OUT;       // luma: 4 row-bands of 16 rows; chroma: 8 bands of 4 rows
     constexpr int BAND = OUT / COLS_PER_WG;
     const int x = tid % OUT, band = tid / OUT;
     for (int y0 = band * BAND; y0 < (band + 1) * BAND; y0 += 4) {
         if (MSBD) {
-            stem_conv<K1, K1, CIN, PS, 4, SPLIT>(planes, wl, bl, 16, x, y0, OUT, out, out_n, 0);
-            stem_conv<K2, K1, CIN, PS, 4, SPLIT>(planes, wl + K1 * K1 * CIN * 16, bl + 16, 8, x, y0, OUT, out, out_n, 16);
-            stem_conv<K1, K2, CIN, PS, 4, SPLIT>(planes, wl + K1 * K1 * CIN * 16 + K2 * K1 * CIN * 8, bl + 24, 8, x, y0, OUT,
+            stem_conv<K1, K1, CIN, PS, 4, FMT>(planes, wl, bl, 16, x, y0, OUT, out, out_n, 0);
+            stem_conv<K2, K1, CIN, PS, 4, FMT>(planes, wl + K1 * K1 * CIN * 16, bl + 16, 8, x, y0, OUT, out, out_n, 16);
+            stem_conv<K1, K2, CIN, PS, 4, FMT>(planes, wl + K1 * K1 * CIN * 16 + K2 * K1 * CIN * 8, bl + 24, 8, x, y0, OUT,
                                           out, out_n, 24);
         } else {
-            stem_conv<K1, K1, CIN, PS, 4, SPLIT>(planes, wl, bl, 32, x, y0, OUT, out, out_n, 0);
+            stem_conv<K1, K1, CIN, PS, 4, FMT>(planes, wl, bl, 32, x, y0, OUT, out, out_n, 0);
         }
     }
 }
@@ -137,8 +137,9 @@ static hipError_t launch_stem_t(hipStream_t s, const StemArgs &a)
     constexpr int K1 = LUMA ? 9 : 5, K2 = LUMA ? 5 : 3;
     constexpr int NW = MSBD ? (K1 * K1 * CIN * 16 + 2 * K2 * K1 * CIN * 8) : (K1 * K1 * CIN * 32);
     const size_t smem = (size_t)(CIN * PS * PS + NW + 32) * sizeof(float);
-    if (a.out_s3) hipLaunchKernelGGL((stem_kernel<LUMA, MSBD, true>), dim3(a.N), dim3(256), smem, s, a);
-    else hipLaunchKernelGGL((stem_kernel<LUMA, MSBD, false>), dim3(a.N), dim3(256), smem, s, a);
+    if (a.out_s3 && a.fmt == FMT_H2) hipLaunchKernelGGL((stem_kernel<LUMA, MSBD, FMT_H2>), dim3(a.N), dim3(256), smem, s, a);
+    else if (a.out_s3) hipLaunchKernelGGL((stem_kernel<LUMA, MSBD, FMT_B3>), dim3(a.N), dim3(256), smem, s, a);
+    else hipLaunchKernelGGL((stem_kernel<LUMA, MSBD, FMT_F32>), dim3(a.N), dim3(256), smem, s, a);
     return hipGetLastError();
 }
 
@@ -275,9 +276,9 @@ __global__ __launch_bounds__(256) void multipool_concat_kernel(const float *__re
     }
 }
 
-hipError_t launch_multipool_concat(hipStream_t s, const float *x5, float *x6, int N, unsigned short *x6_s3, size_t s3_stride)
+hipError_t launch_multipool_concat(hipStream_t s, const float *x5, float *x6, int N, unsigned short *x6_s3, size_t s3_stride, int fmt)
 {
-    hipLaunchKernelGGL(multipool_concat_kernel, dim3(N * 2), dim3(256), 0, s, x5, ActOut{x6, x6_s3, s3_stride});
+    hipLaunchKernelGGL(multipool_concat_kernel, dim3(N * 2), dim3(256), 0, s, x5, ActOut{x6, x6_s3, s3_stride, fmt});
     return hipGetLastError();
 }
 
@@ -297,11 +298,11 @@ __global__ __launch_bounds__(256) void att_input_kernel(const float *__restrict_
 }
 
 hipError_t launch_att_input(hipStream_t s, const float *q, const float *bt, const float *dire, int layer, float *out,
-                            int N, int S, unsigned short *out_s3, size_t s3_stride)
+                            int N, int S, unsigned short *out_s3, size_t s3_stride, int fmt)
 {
     const size_t total = (size_t)N * S * S;
     hipLaunchKernelGGL(att_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, q, bt, dire, layer,
-                       ActOut{out, out_s3, s3_stride}, N, S);
+                       ActOut{out, out_s3, s3_stride, fmt}, N, S);
     return hipGetLastError();
 }
 

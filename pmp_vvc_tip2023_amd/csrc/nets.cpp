@@ -11,6 +11,8 @@
 // In bf16x6 mode tensors that only feed MFMA convs stay split-3; tensors read by the small fp32 kernels (heads,
 // 8x8 tail, multi-scale pool, attention inputs) are written as fp32 by the producing conv, and the three fp32-born
 // inputs of MFMA convs (stem output, x6, attention inputs) pass through a split kernel.
+#include <cmath>
+
 #include "pmp_host.h"
 
 namespace pmp {
@@ -18,7 +20,7 @@ namespace pmp {
 namespace {
 
 struct Act {
-    float *p;      // fp32 tensor, or the first of three bf16 planes when split
+    float *p;      // fp32 tensor, or the first split plane (three bf16 / two fp16 planes)
     int C, H, W;   // C padded to 16
     bool split;
     size_t stride; // elements between split planes
@@ -31,14 +33,16 @@ struct Graph {
     const NetWeights &w;
     int n;
     int rc = PMP_OK;
-    bool x6() const { return c->precision == 1; }
+    bool x6() const { return c->precision != 0; }      // a split datapath (bf16x6 or f16x3) is active
+    bool h2() const { return c->precision == 2; }
+    int fmt() const { return c->precision; }           // split3.h: 0 fp32, 1 split-3, 2 split-2
 
     Act alloc(int C, int H, int W, bool split)
     {
         const int cp = (C + 15) & ~15;
         const size_t elems = (size_t)c->chunk * cp * H * W;
-        // split-3: 3 planes of 2-byte elements = 1.5 floats per element
-        float *p = c->arena.get(split ? (elems * 3 + 1) / 2 : elems);
+        // split-3: 3 planes of 2-byte elements = 1.5 floats per element; split-2: 2 planes = 1 float per element
+        float *p = c->arena.get(split && !h2() ? (elems * 3 + 1) / 2 : elems);
         return Act{p, cp, H, W, split, elems};
     }
 
@@ -63,7 +67,8 @@ struct Graph {
         Act y = alloc(x.C, x.H, x.W, true);
         if (live()) {
             KScope ks(c, K_SMALL, 0.0);
-            check(launch_f32_to_split3(c->stream, x.p, y.s(), (size_t)n * x.C * x.H * x.W, y.stride), "f32_to_split3");
+            if (h2()) check(launch_f32_to_split2(c->stream, x.p, y.s(), (size_t)n * x.C * x.H * x.W, y.stride), "f32_to_split2");
+            else check(launch_f32_to_split3(c->stream, x.p, y.s(), (size_t)n * x.C * x.H * x.W, y.stride), "f32_to_split3");
         }
         return y;
     }
@@ -76,14 +81,17 @@ struct Graph {
         KScope ks(c, cls, flops);
         if (x6()) {
             ConvX6Args a{};
-            a.x = x.s(); a.x_stride = x.stride; a.w = second ? r.w2x : r.w0x;
-            if (sc_src) { a.x_sc = sc_src->s(); a.sc_stride = sc_src->stride; a.w_sc = r.wscx; a.Csc = sc_src->C; }
+            a.x = x.s(); a.x_stride = x.stride;
+            if (h2()) { a.w = second ? r.w2h : r.w0h; a.out_scale = std::ldexp(1.f, -(second ? r.k2 : r.k0)); }
+            else a.w = second ? r.w2x : r.w0x;
+            if (sc_src) { a.x_sc = sc_src->s(); a.sc_stride = sc_src->stride; a.w_sc = h2() ? r.wsch : r.wscx; a.Csc = sc_src->C; }
             if (res) { a.res = res->s(); a.res_stride = res->stride; }
             if (gate) { a.gate = gate->s(); a.gate_stride = gate->stride; }
             if (out.split) { a.out = out.s(); a.out_stride = out.stride; }
             else a.out_f32 = out.p;
             a.N = n; a.H = x.H; a.W = x.W; a.Cin = x.C; a.Cout = out.C; a.KH = a.KW = r.k; a.relu = 1; a.pool = pool ? 1 : 0;
-            check(launch_conv_x6(c->stream, a), "conv_x6");
+            if (h2()) check(launch_conv_h2(c->stream, a), "conv_h2");
+            else check(launch_conv_x6(c->stream, a), "conv_x6");
         } else {
             ConvMfmaArgs a{};
             a.x = x.p; a.w = second ? r.w2 : r.w0; a.out = out.p;
@@ -135,7 +143,7 @@ struct Graph {
         const int S = luma ? 64 : 32;
         Act o = alloc(32, S, S, x6());     // bf16x6 mode: the stem writes split-3 planes directly
         if (!live()) return o;
-        StemArgs a{by, bu, bv, q, w.stem_w, w.stem_b, o.split ? nullptr : o.p, n, o.split ? o.s() : nullptr, o.stride};
+        StemArgs a{by, bu, bv, q, w.stem_w, w.stem_b, o.split ? nullptr : o.p, n, o.split ? o.s() : nullptr, o.stride, fmt()};
         const int cin = (luma ? 1 : 3) + (msbd ? 1 : 0), k1 = luma ? 9 : 5, k2 = luma ? 5 : 3;
         const double macs = msbd ? (double)cin * (k1 * k1 * 16 + 2 * k1 * k2 * 8) : (double)cin * k1 * k1 * 32;
         KScope ks(c, K_STEM, 2.0 * n * S * S * macs);
@@ -166,7 +174,7 @@ int forward_q(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, con
     Act x6 = g.alloc(128, 16, 16, g.x6());
     if (g.live()) {
         KScope ks(c, K_SMALL, 0.0);
-        g.check(launch_multipool_concat(c->stream, x5.p, x6.split ? nullptr : x6.p, n, x6.split ? x6.s() : nullptr, x6.stride), "multipool_concat");
+        g.check(launch_multipool_concat(c->stream, x5.p, x6.split ? nullptr : x6.p, n, x6.split ? x6.s() : nullptr, x6.stride, g.fmt()), "multipool_concat");
     }
     Act x7 = g.rb(x6, "resblock_q4");
     Act x8 = g.rb(x7, "resblock_q5", true, nullptr, true);    // fp32: 8x8 tail runs on the direct kernel
@@ -194,7 +202,7 @@ int forward_msbd(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, 
     Act ai = g.alloc(16, 16, 16, g.x6());
     if (g.live()) {
         KScope ks(c, K_SMALL, 0.0);
-        g.check(launch_att_input(c->stream, qt, bt, dire, 0, ai.split ? nullptr : ai.p, n, 16, ai.split ? ai.s() : nullptr, ai.stride), "att_input");
+        g.check(launch_att_input(c->stream, qt, bt, dire, 0, ai.split ? nullptr : ai.p, n, 16, ai.split ? ai.s() : nullptr, ai.stride, g.fmt()), "att_input");
     }
     Act xb1 = g.rb(g.rb(ai, "trunk_Att1.0"), "trunk_Att1.1", false, &x5);
     b = g.rb(g.rb(g.rb(xb1, "trunk_B2.0"), "trunk_B2.1"), "trunk_B2.2", false, nullptr, true);
@@ -203,7 +211,7 @@ int forward_msbd(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, 
     Act aj = g.alloc(16, 32, 32, g.x6());
     if (g.live()) {
         KScope ks(c, K_SMALL, 0.0);
-        g.check(launch_att_input(c->stream, qt, bt, dire, 1, aj.split ? nullptr : aj.p, n, 32, aj.split ? aj.s() : nullptr, aj.stride), "att_input");
+        g.check(launch_att_input(c->stream, qt, bt, dire, 1, aj.split ? nullptr : aj.p, n, 32, aj.split ? aj.s() : nullptr, aj.stride, g.fmt()), "att_input");
     }
     Act xb3 = g.rb(g.rb(aj, "trunk_Att2.0"), "trunk_Att2.1", false, &x4);
     b = g.rb(g.rb(g.rb(xb3, "trunk_B3.0"), "trunk_B3.1"), "trunk_B3.2", true, nullptr, true);

@@ -220,7 +220,8 @@ int pmp_set_chunk(pmp_ctx *c, int blocks)
 int pmp_set_precision(pmp_ctx *c, int mode)
 {
     CHECK_CTX(c);
-    if (mode != PMP_PRECISION_F32 && mode != PMP_PRECISION_BF16X6) return set_err(c, PMP_E_INVALID, "pmp_set_precision: 0 (fp32) or 1 (bf16x6)");
+    if (mode != PMP_PRECISION_F32 && mode != PMP_PRECISION_BF16X6 && mode != PMP_PRECISION_F16X3)
+        return set_err(c, PMP_E_INVALID, "pmp_set_precision: 0 (fp32), 1 (bf16x6) or 2 (f16x3)");
     int rc = sync(c);
     if (rc != PMP_OK) return rc;
     c->precision = mode;
@@ -520,7 +521,9 @@ int pmp_debug_conv_bench(pmp_ctx *c, int n, int h, int w, int cin, int cout, int
     const float ws = 1.f / sqrtf((float)cin * k * k);
     for (auto &v : hw) v = rnd() * ws;
     std::vector<float> wp = pack_mfma(hw.data(), cout, cin, k, k, cout, cin);
-    std::vector<unsigned short> wx = pack_x6(hw.data(), cout, cin, k, k, cout, cin);
+    const bool h2 = c->precision == PMP_PRECISION_F16X3;   // the split leg follows the context's datapath
+    const int kexp = h2_scale_exp(hw.data(), hw.size());
+    std::vector<unsigned short> wx = h2 ? pack_h2(hw.data(), cout, cin, k, k, cout, cin, kexp) : pack_x6(hw.data(), cout, cin, k, k, cout, cin);
     float *dx = nullptr, *dy = nullptr, *dy2 = nullptr, *dwp = nullptr;
     unsigned short *dxs = nullptr, *dys = nullptr, *dwx = nullptr;
     hipError_t e = hipSuccess;
@@ -538,21 +541,24 @@ int pmp_debug_conv_bench(pmp_ctx *c, int n, int h, int w, int cin, int cout, int
         ConvX6Args b{};
         b.x = dxs; b.x_stride = nx; b.w = dwx; b.out = dys; b.out_stride = ny;
         b.N = n; b.H = h; b.W = w; b.Cin = cin; b.Cout = cout; b.KH = b.KW = k; b.relu = 1;
+        b.out_scale = std::ldexp(1.f, -kexp);
+        auto launch_split = [&]() { return h2 ? launch_conv_h2(c->stream, b) : launch_conv_x6(c->stream, b); };
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
-        launch_f32_to_split3(c->stream, dx, dxs, nx, nx);
+        if (h2) launch_f32_to_split2(c->stream, dx, dxs, nx, nx);
+        else launch_f32_to_split3(c->stream, dx, dxs, nx, nx);
         launch_conv_mfma(c->stream, a);
-        e = launch_conv_x6(c->stream, b);
+        e = launch_split();
         float ms = 0.f;
         hipEventRecord(e0, c->stream);
         for (int i = 0; i < iters; ++i) launch_conv_mfma(c->stream, a);
         hipEventRecord(e1, c->stream); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
         if (ms_f32) *ms_f32 = ms / iters;
         hipEventRecord(e0, c->stream);
-        for (int i = 0; i < iters; ++i) launch_conv_x6(c->stream, b);
+        for (int i = 0; i < iters; ++i) launch_split();
         hipEventRecord(e1, c->stream); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
         if (ms_x6) *ms_x6 = ms / iters;
-        if (g_conv_variant == 10 + 128 && k == 3 && cout == 64) {   // in-kernel stamp report (diagnostic build)
+        if (!h2 && g_conv_variant == 10 + 128 && k == 3 && cout == 64) {   // in-kernel stamp report (diagnostic build)
             const int wgs = n * (h / 16) * (w / 16);
             unsigned long long *ddbg = nullptr;
             if (hipMalloc((void **)&ddbg, (size_t)wgs * 8 * 8) == hipSuccess) {
@@ -576,7 +582,8 @@ int pmp_debug_conv_bench(pmp_ctx *c, int n, int h, int w, int cin, int cout, int
                 hipFree(ddbg);
             }
         }
-        launch_split3_to_f32(c->stream, dys, dy2, ny, ny);
+        if (h2) launch_split2_to_f32(c->stream, dys, dy2, ny, ny);
+        else launch_split3_to_f32(c->stream, dys, dy2, ny, ny);
         std::vector<float> y1(ny), y2(ny);
         hipMemcpyAsync(y1.data(), dy, ny * 4, hipMemcpyDeviceToHost, c->stream);
         hipMemcpyAsync(y2.data(), dy2, ny * 4, hipMemcpyDeviceToHost, c->stream);

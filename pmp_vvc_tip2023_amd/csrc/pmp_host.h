@@ -25,6 +25,8 @@ struct RBWeights {
     int cin_pad = 0, cout_pad = 0;
     float *w0 = nullptr, *w2 = nullptr, *wsc = nullptr;  // fp32 MFMA packing (or direct packing when `direct`)
     unsigned short *w0x = nullptr, *w2x = nullptr, *wscx = nullptr;  // bf16x6 split packing (conv_bf16x6.hip)
+    unsigned short *w0h = nullptr, *w2h = nullptr, *wsch = nullptr;  // f16x3 split packing (conv_f16x3.hip), scaled by
+    int k0 = 0, k2 = 0;                                               // 2^k0 (first conv) / 2^k2 (second conv + shortcut)
     bool direct = false;               // 8x8 layers run on the direct kernel
 };
 
@@ -58,7 +60,7 @@ struct pmp_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     int chunk = 1024;
-    int precision = 1;                     // 0: fp32 MFMA, 1: bf16x6 split (fp32-equivalent, default)
+    int precision = 2;                     // 0: fp32 MFMA, 1: bf16x6 split, 2: f16x3 split (default; both splits fp32-equivalent)
     std::string err;
     std::map<int, pmp::NetWeights> nets;  // key = net_id * 100 + qp
     pmp::Arena arena;
@@ -82,6 +84,8 @@ int load_net_weights(pmp_ctx *c, int net_id, int qp, const float *blob, const pm
 void free_net_weights(NetWeights &w);
 std::vector<float> pack_mfma(const float *w, int cout, int cin, int kh, int kw, int cout_pad, int cin_pad);
 std::vector<unsigned short> pack_x6(const float *w, int cout, int cin, int kh, int kw, int cout_pad, int cin_pad);
+std::vector<unsigned short> pack_h2(const float *w, int cout, int cin, int kh, int kw, int cout_pad, int cin_pad, int scale_exp);
+int h2_scale_exp(const float *w, size_t n);
 
 // nets.cpp: forward graphs on device pointers (n <= chunk); all launches go to c->stream.
 int forward_q(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, const uint8_t *bu, const uint8_t *bv,

@@ -48,15 +48,63 @@ struct GeoX {
     static constexpr int NLD = (PIECES + 255) / 256;
 };
 
-// fp32 blocked tensor or split-3 planes behind one store call (elements, not bytes, index both)
+// ---- "split-2": v = h0 + h1 with two fp16 terms (22 significand bits; conv_f16x3.hip).  Values beyond the fp16 range are
+// clamped to +-65504 (the reference's activations stay below 3e3 on every test input, tools/precision_study.py).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split2(float v, _Float16 &a, _Float16 &b)
+{
+    v = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+    a = (_Float16)v;
+    b = (_Float16)(v - (float)a);   // v - a is exact in fp32; b keeps its leading 11 bits
+}
+
+__device__ __forceinline__ f32x4 load_split2_4(const unsigned short *p, size_t plane_stride)
+{
+    const f16x4 a = *reinterpret_cast<const f16x4 *>(p), b = *reinterpret_cast<const f16x4 *>(p + plane_stride);
+    f32x4 v;
+    v.x = (float)a.x + (float)b.x; v.y = (float)a.y + (float)b.y; v.z = (float)a.z + (float)b.z; v.w = (float)a.w + (float)b.w;
+    return v;
+}
+
+__device__ __forceinline__ void store_split2_4(unsigned short *p, size_t plane_stride, f32x4 v)
+{
+    _Float16 a0, a1, a2, a3, b0, b1, b2, b3;
+    split2(v.x, a0, b0); split2(v.y, a1, b1); split2(v.z, a2, b2); split2(v.w, a3, b3);
+    const f16x4 a = {a0, a1, a2, a3}, b = {b0, b1, b2, b3};
+    *reinterpret_cast<f16x4 *>(p) = a;
+    *reinterpret_cast<f16x4 *>(p + plane_stride) = b;
+}
+
+// Activation formats: 0 = plain fp32, 1 = split-3 (three bf16 planes), 2 = split-2 (two fp16 planes).
+enum { FMT_F32 = 0, FMT_B3 = 1, FMT_H2 = 2 };
+
+template <int FMT>
+__device__ __forceinline__ f32x4 load_fmt4(const unsigned short *p, size_t plane_stride)
+{
+    if (FMT == FMT_H2) return load_split2_4(p, plane_stride);
+    return load_split4(p, plane_stride);
+}
+
+template <int FMT>
+__device__ __forceinline__ void store_fmt4(unsigned short *p, size_t plane_stride, f32x4 v)
+{
+    if (FMT == FMT_H2) store_split2_4(p, plane_stride, v);
+    else store_split4(p, plane_stride, v);
+}
+
+// fp32 blocked tensor or split planes behind one store call (elements, not bytes, index both)
 struct ActOut {
     float *f32;
-    unsigned short *s3;
+    unsigned short *s3;   // first split plane (format `fmt`), or nullptr for fp32 output
     size_t stride;
+    int fmt;
     __device__ __forceinline__ void store4(size_t elem, f32x4 v) const
     {
-        if (s3) store_split4(s3 + elem, stride, v);
-        else *reinterpret_cast<f32x4 *>(f32 + elem) = v;
+        if (!s3) *reinterpret_cast<f32x4 *>(f32 + elem) = v;
+        else if (fmt == FMT_H2) store_split2_4(s3 + elem, stride, v);
+        else store_split4(s3 + elem, stride, v);
     }
 };
 

@@ -3,6 +3,8 @@
 // Counterpart of load_pretrain_model (Inference_QBD.py:28-46): tensors are matched by name and shape; a missing or
 // mis-shaped tensor is an error (the reference silently keeps random init for such tensors, which would be a
 // silent accuracy bug here).
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <utility>
 
@@ -134,6 +136,54 @@ std::vector<unsigned short> pack_x6(const float *w, int cout, int cin, int kh, i
     return out;
 }
 
+// Power-of-two scale for the fp16 split (conv_f16x3.hip): S = 2^k with max|S*w| in [4096, 8192); k in [0, 24].
+int h2_scale_exp(const float *w, size_t n)
+{
+    float m = 0.f;
+    for (size_t i = 0; i < n; ++i) m = std::fmax(m, std::fabs(w[i]));
+    if (!(m > 0.f) || !std::isfinite(m)) return 0;
+    int e = 0;
+    std::frexp(m, &e);            // m = f * 2^e, f in [0.5, 1)
+    int k = 13 - e;               // S*m = f * 2^13 in [4096, 8192)
+    return k < 0 ? 0 : (k > 24 ? 24 : k);
+}
+
+// Same K-step stream as pack_x6, two fp16 terms of S*w per element: [step][2 splits][cout_pad/16][64 lanes][8].
+std::vector<unsigned short> pack_h2(const float *w, int cout, int cin, int kh, int kw, int cout_pad, int cin_pad, int scale_exp)
+{
+    const int taps = kh * kw, CB = cin_pad / 16, NT = cout_pad / 16;
+    const bool paired = (CB % 2 == 0) && (taps % 2 == 1);
+    const float S = std::ldexp(1.f, scale_exp);
+    struct Half { int cb, tap; };
+    std::vector<std::pair<Half, Half>> steps;
+    if (paired) {
+        for (int cb = 0; cb < CB; ++cb) {
+            if (cb & 1) steps.push_back({{cb - 1, taps - 1}, {cb, taps - 1}});
+            for (int ks = 0; ks < (taps - 1) / 2; ++ks) steps.push_back({{cb, 2 * ks}, {cb, 2 * ks + 1}});
+        }
+    } else {
+        for (int cb = 0; cb < CB; ++cb)
+            for (int ks = 0; ks < (taps + 1) / 2; ++ks) steps.push_back({{cb, 2 * ks}, {cb, 2 * ks + 1}});
+    }
+    auto bits = [](_Float16 h) { unsigned short u; std::memcpy(&u, &h, 2); return u; };
+    std::vector<unsigned short> out(steps.size() * 2 * NT * 64 * 8, 0);
+    for (size_t st = 0; st < steps.size(); ++st)
+        for (int nt = 0; nt < NT; ++nt)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int g = l >> 4;
+                    const Half h = (g >> 1) ? steps[st].second : steps[st].first;
+                    const int co = nt * 16 + (l & 15), ci = h.cb * 16 + 8 * (g & 1) + j, t = h.tap;
+                    float v = 0.f;
+                    if (co < cout && ci < cin && t < taps) v = w[((size_t)co * cin + ci) * taps + t] * S;
+                    const _Float16 h0 = (_Float16)v;
+                    const _Float16 h1 = (_Float16)(v - (float)h0);
+                    out[(((st * 2 + 0) * NT + nt) * 64 + l) * 8 + j] = bits(h0);
+                    out[(((st * 2 + 1) * NT + nt) * 64 + l) * 8 + j] = bits(h1);
+                }
+    return out;
+}
+
 namespace {
 
 // OIHW -> [tap][cin][cout] (direct kernels, stems, heads)
@@ -180,6 +230,13 @@ int load_rb(pmp_ctx *c, const Blob &b, Uploader &up, const std::string &name, in
         if ((rc = up.upload16(pack_x6(w0, cout, cin, k, k, r.cout_pad, r.cin_pad), &r.w0x))) return rc;
         if ((rc = up.upload16(pack_x6(w2, cout, cout, k, k, r.cout_pad, r.cout_pad), &r.w2x))) return rc;
         if (wsc && (rc = up.upload16(pack_x6(wsc, cout, cin, 1, 1, r.cout_pad, r.cin_pad), &r.wscx))) return rc;
+        // fp16 split: the second conv and the 1x1 shortcut accumulate into one tile, so they share one scale
+        r.k0 = h2_scale_exp(w0, (size_t)cout * cin * k * k);
+        r.k2 = h2_scale_exp(w2, (size_t)cout * cout * k * k);
+        if (wsc) r.k2 = std::min(r.k2, h2_scale_exp(wsc, (size_t)cout * cin));
+        if ((rc = up.upload16(pack_h2(w0, cout, cin, k, k, r.cout_pad, r.cin_pad, r.k0), &r.w0h))) return rc;
+        if ((rc = up.upload16(pack_h2(w2, cout, cout, k, k, r.cout_pad, r.cout_pad, r.k2), &r.w2h))) return rc;
+        if (wsc && (rc = up.upload16(pack_h2(wsc, cout, cin, 1, 1, r.cout_pad, r.cin_pad, r.k2), &r.wsch))) return rc;
     }
     up.nw->rb[name] = r;
     return PMP_OK;

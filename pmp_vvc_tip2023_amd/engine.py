@@ -63,11 +63,12 @@ class Engine:
         self._ck(self.lib.pmp_set_chunk(self.h, int(blocks)))
 
     def set_precision(self, mode):
-        """'bf16x6' (default; 3-term bf16 split, 6 MFMA products, fp32-equivalent) or 'fp32' (exact fp32 MFMA)."""
-        self._ck(self.lib.pmp_set_precision(self.h, {"fp32": 0, "f32": 0, "bf16x6": 1}[mode]))
+        """'f16x3' (default; 2-term fp16 split, 3 MFMA products), 'bf16x6' (3-term bf16 split, 6 products) - both
+        fp32-equivalent - or 'fp32' (exact fp32 MFMA)."""
+        self._ck(self.lib.pmp_set_precision(self.h, {"fp32": 0, "f32": 0, "bf16x6": 1, "f16x3": 2}[mode]))
 
     def get_precision(self):
-        return {0: "fp32", 1: "bf16x6"}[self.lib.pmp_get_precision(self.h)]
+        return {0: "fp32", 1: "bf16x6", 2: "f16x3"}[self.lib.pmp_get_precision(self.h)]
 
     def synchronize(self):
         self._ck(self.lib.pmp_synchronize(self.h))

@@ -10,9 +10,9 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3  # north_star: "within 1e-3 fp32 on the map logits"
 
 
-@pytest.fixture(scope="module", params=["bf16x6", "fp32"])
+@pytest.fixture(scope="module", params=["f16x3", "bf16x6", "fp32"])
 def eng(request):
-    """Every parity test runs on both convolution datapaths (default bf16x6 split and exact fp32 MFMA)."""
+    """Every parity test runs on all three convolution datapaths (fp16 2-term split, bf16 3-term split, exact fp32 MFMA)."""
     from pmp_vvc_tip2023_amd import engine
     e = engine.Engine(0)
     e.set_precision(request.param)

@@ -1,8 +1,12 @@
-"""One conv layer, fp32-MFMA kernel vs bf16x6 split kernel, random data (run on the GPU box)."""
+"""One conv layer, fp32-MFMA kernel vs a split kernel (bf16x6, or f16x3 with `h2` as first argument), random data (run on the GPU box)."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pmp_vvc_tip2023_amd import engine
 eng = engine.Engine(0)
+split = "bf16x6"
+if len(sys.argv) > 1 and sys.argv[1] == "h2":
+    split = "f16x3"; del sys.argv[1]
+eng.set_precision(split)
 shapes = [(256, 64, 64, 64, 64, 3), (256, 64, 64, 64, 64, 5), (256, 64, 64, 32, 64, 5), (512, 32, 32, 64, 64, 3), (512, 16, 16, 64, 32, 3), (512, 16, 16, 32, 16, 3)]
 abl = [0]
 if len(sys.argv) > 1 and sys.argv[1] == "ablate":
@@ -17,5 +21,5 @@ for ab in abl:
     a, b, d, r = C.c_double(), C.c_double(), C.c_double(), C.c_double()
     eng._ck(eng.lib.pmp_debug_conv_bench(eng.h, n, h, w, ci, co, k, 10, C.byref(a), C.byref(b), C.byref(d), C.byref(r)))
     fl = 2.0 * n * h * w * co * ci * k * k
-    print("n%d %dx%d %d->%d k%d: fp32 %.3f ms (%.0f TF)  bf16x6 %.3f ms (%.0f TF)  speedup %.2fx  max|diff| %.2e (max|ref| %.1f)" % (
+    print(("n%d %dx%d %d->%d k%d: fp32 %.3f ms (%.0f TF)  " + split + " %.3f ms (%.0f TF)  speedup %.2fx  max|diff| %.2e (max|ref| %.1f)") % (
         n, h, w, ci, co, k, a.value, fl / a.value / 1e9, b.value, fl / b.value / 1e9, a.value / b.value, d.value, r.value), flush=True)
