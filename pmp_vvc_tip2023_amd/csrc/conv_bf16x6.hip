@@ -216,6 +216,9 @@ __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__
                 for (int nt = 0; nt < NT; ++nt) w0[nt] = wk[(0 * NT + nt) * 64];
             }
             __builtin_amdgcn_sched_barrier(0);
+            // The cross-group K-step is the only one that reads the OTHER halo buffer; every wave must be past it before any
+            // wave overwrites that buffer at the end of this group (the waves of a workgroup are only loosely in step).
+            if (MODE == 2 && ks == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         if (ABL & 128) { const unsigned long long t = stamp_now(); t_k += t - tmark; tmark = t; }
         // the partner buffer is only overwritten here, after the last K-step that may read the previous group from it

@@ -16,10 +16,9 @@
 // group), plane stride = N*C*H*W elements.  Tiling, LDS image, tap pairing and the weight stream order are those of
 // conv_bf16x6.hip (one workgroup = 16x16 pixels x all Cout, wave = 4 rows, K-step = 16 channels x a pair of taps).
 //
-// K-step schedule (48 MFMAs at Cout = 64).  Weights sit in TWO register sets: the next K-step's fragments are requested at
-// the top of a K-step, one full K-step before their first use; set parity is static (outer loops unrolled by two).
-//   phase A: x0*w1, x0*w0   (x1 fragments of this K-step and x0 of the next arrive meanwhile)
-//   phase B: x1*w0
+// K-step schedule (48 MFMAs at Cout = 64).  ONE weight register set, refilled in place from the L2-resident stream as
+// soon as the last MFMA that reads a split has issued:
+//   phase A: x0*w1 -> request the next w1     phase B1: x0*w0 -> read the next K-step's x0     phase B2: x1*w0 -> request w0
 #include <type_traits>
 
 #include "pmp_kernels.h"
@@ -83,161 +82,202 @@ __device__ __forceinline__ void h2_stage_store(const StagePlanH<KH, KW> &p, u32x
     }
 }
 
-template <int KH, int KW, int NT>
+// Wave tile: RW rows x CW cout groups of the workgroup's 16 rows x NT groups (4 waves).  At Cout >= 32 a wave takes 8 rows
+// and half (or all) of the cout groups: it then streams half of the weight bytes per MFMA from L2 - the vector-memory
+// path is the contended one here - and reads twice the pixel fragments from LDS, which has the headroom.
+template <int NT>
+struct WaveTile {
+    static constexpr int RW = NT >= 2 ? 8 : 4;        // rows per wave
+    static constexpr int CW = NT * RW >= 16 ? NT * RW / 16 : 1;   // cout groups per wave
+    static constexpr int RSPLIT = 16 / RW;            // waves along the rows
+};
+
+template <int KH, int KW, int NT, int ABL = 0>
 __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__ x, size_t plane_stride,
                                               const unsigned short *__restrict__ wpk, int C, int H, int W, int n, int ty,
-                                              int tx, u32x4 *lds, f32x4 (&acc)[4][NT])
+                                              int tx, u32x4 *lds, f32x4 (&acc)[WaveTile<NT>::RW][WaveTile<NT>::CW])
 {
     typedef GeoH<KH, KW> G;
+    typedef WaveTile<NT> WT;
+    constexpr int RW = WT::RW, CW = WT::CW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, xl = lane & 15, g = lane >> 4;
+    const int rh = wave % WT::RSPLIT, ch = wave / WT::RSPLIT;   // this wave: rows RW*rh.., cout groups CW*ch..
     const int CB = C >> 4;
     const size_t grp_sz = (size_t)H * W * 16;
     const unsigned short *grp0 = x + (size_t)n * CB * grp_sz;
-    u32x4 r[G::NLD];
+    // Halo staging registers.  With tap pairing (even group count) there are TWO sets: group g+2 is requested during group
+    // g and written to LDS at the end of group g+1, so an HBM round trip has two groups of MFMAs to hide behind (loaded
+    // latency here is longer than one 3x3 group).  Plain mode keeps one set and a distance of one group.
+    constexpr bool DEEP = G::TAPS <= 9;   // 5x5 groups (12.5 K-steps) outlast the HBM latency on their own
+    u32x4 r[G::NLD], rb[DEEP ? G::NLD : 1];
     StagePlanH<KH, KW> plan;
     h2_plan<KH, KW>(plan, plane_stride, H, W, ty, tx);
     // Tap pairing as in conv_bf16x6.hip: mode 0 plain (last pair zero-padded), mode 1 even group of a pair (its last tap
-    // is deferred), mode 2 odd group (first K-step = the deferred tap, read from the other LDS buffer, + its own last tap).
+    // is deferred and carried in registers), mode 2 odd group (first K-step = the deferred tap + its own last tap).
     const bool paired = (CB & 1) == 0 && (G::TAPS & 1);
-    const f16x8 *wl = reinterpret_cast<const f16x8 *>(wpk) + lane;
+    const f16x8 *wl = reinterpret_cast<const f16x8 *>(wpk) + lane + ch * CW * 64;
     const int last = paired ? (CB / 2) * G::TAPS - 1 : CB * G::NKS - 1;   // last K-step of the weight stream
-    f16x8 wa0[NT], wa1[NT], wb0[NT], wb1[NT];   // two weight sets (a: even K-steps of the stream, b: odd), splits 0 and 1
+    f16x8 w0[CW], w1[CW];   // ONE weight set, refilled in place as soon as the last MFMA that reads a split has issued
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { wa0[nt] = wl[(0 * NT + nt) * 64]; wa1[nt] = wl[(1 * NT + nt) * 64]; }
+    for (int nt = 0; nt < CW; ++nt) { w0[nt] = wl[(0 * NT + nt) * 64]; w1[nt] = wl[(1 * NT + nt) * 64]; }
     __syncthreads();
     h2_stage_load<KH, KW>(plan, grp0, r);
+    if (DEEP && paired) h2_stage_load<KH, KW>(plan, grp0 + grp_sz, reinterpret_cast<u32x4 (&)[G::NLD]>(rb));   // group 1 exists: CB is even
     h2_stage_store<KH, KW>(plan, lds, r);
     __syncthreads();
-    const int pb = ((wave * 4 * G::TW + xl) * 2 + (g & 1)) * 16;   // bytes inside a split plane, tap (0,0)
+    // ABL: timing-only builds (tools/conv_x6_bench.py h2 ablate): 1 no halo staging, 2 no weight refills, 4 no fragment reads, 8 no epilogue
+    const int pb = ((rh * RW * G::TW + xl) * 2 + (g & 1)) * 16;   // bytes inside a split plane, tap (0,0)
     int stream = 0;
     int tapsel = g >> 1;
+    constexpr int O_LAST = (((G::TAPS - 1) / KW) * G::TW + (G::TAPS - 1) % KW) * 32;   // byte offset of the last tap
+    f16x8 x0[RW], x1[RW];   // pixel fragments of the current K-step (split 0 / split 1)
 
-    auto group = [&](auto mode_tag, auto par_tag, int cb) {
-        constexpr int MODE = decltype(mode_tag)::value, PAR0 = decltype(par_tag)::value;
+    auto group = [&](auto mode_tag, int cb) {
+        constexpr int MODE = decltype(mode_tag)::value;
         constexpr int NK = MODE == 0 ? G::NKS : (MODE == 1 ? (G::TAPS - 1) / 2 : (G::TAPS - 1) / 2 + 1);
         constexpr int PER = (G::NLD + (NK > 0 ? NK : 1) - 1) / (NK > 0 ? NK : 1);   // staging loads issued per K-step
+        constexpr int DIST = (MODE == 0 || !DEEP) ? 1 : 2;   // groups between a halo request and its LDS store
+        u32x4 (&rbb)[G::NLD] = reinterpret_cast<u32x4 (&)[G::NLD]>(rb);
+        u32x4 (&rl)[G::NLD] = (DIST == 2 && MODE == 2) ? rbb : r;   // requested during this group
+        u32x4 (&rs)[G::NLD] = (DIST == 2 && MODE == 1) ? rbb : r;   // written to LDS at the end of this group (for group cb+1)
         const bool more = cb + 1 < CB;
-        const unsigned short *nxt_grp = grp0 + (size_t)min(cb + 1, CB - 1) * grp_sz;   // clamped: loads stay unconditional
+        const unsigned short *nxt_grp = grp0 + (size_t)min(cb + DIST, CB - 1) * grp_sz;   // clamped: loads stay unconditional
         const char *buf = reinterpret_cast<const char *>(lds + (cb & 1) * G::PIECES);
-        const char *prv = reinterpret_cast<const char *>(lds + ((cb + 1) & 1) * G::PIECES);
-        auto xaddr = [&](int ks) -> const char * {
-            int tA = 2 * ks, tB = 2 * ks + 1;
-            bool prevA = false;
+        auto xaddr = [&](int ks) -> const char * {   // in-group tap pair of K-step ks
+            const int j = MODE == 2 ? ks - 1 : ks;
+            int tA = 2 * j, tB = 2 * j + 1;
             if (MODE == 0 && tB >= G::TAPS) tB = tA;
-            if (MODE == 2) {
-                if (ks == 0) { tA = tB = G::TAPS - 1; prevA = true; }
-                else { tA = 2 * (ks - 1); tB = tA + 1; }
-            }
             const int oA = ((tA / KW) * G::TW + tA % KW) * 32, oB = ((tB / KW) * G::TW + tB % KW) * 32;
-            return (tapsel ? buf + oB : (prevA ? prv : buf) + oA) + pb;
+            return buf + (tapsel ? oB : oA) + pb;
         };
-        f16x8 xa[4], xb[4], x1[4];   // x0 fragments alternate between xa (even K-steps of the group) and xb (odd)
         if (NK == 0) {   // 1x1 source, even group: nothing to compute yet, only fetch the partner group
-            h2_stage_load<KH, KW>(plan, nxt_grp, r);
-        } else {
-            const char *p0 = xaddr(0);
+            if (!(ABL & 1)) h2_stage_load<KH, KW>(plan, nxt_grp, rl);
+        } else if (MODE == 2) {
+            // cross-group pair: lanes g < 2 still hold the even group's last tap (picked up before the barrier that ended
+            // it - that buffer is being overwritten by now), lanes g >= 2 read this group's last tap
+            if (g >= 2) {
+                const char *pl = buf + O_LAST + pb;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) xa[m] = *reinterpret_cast<const f16x8 *>(p0 + m * G::TW * 32);
+                for (int m = 0; m < RW; ++m) {
+                    x0[m] = *reinterpret_cast<const f16x8 *>(pl + m * G::TW * 32);
+                    x1[m] = *reinterpret_cast<const f16x8 *>(pl + G::PLANE * 16 + m * G::TW * 32);
+                }
+            }
+        } else {
+            const char *p0x = xaddr(0);
+#pragma unroll
+            for (int m = 0; m < RW; ++m) x0[m] = *reinterpret_cast<const f16x8 *>(p0x + m * G::TW * 32);
         }
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) {
             asm volatile("" : "+v"(tapsel));   // keeps hipcc from hoisting every K-step's tap offset out of the group loop
-            const char *px = xaddr(ks);
+            const char *px = (MODE == 2 && ks == 0) ? buf : xaddr(ks);
             ++stream;
-            const f16x8 *wk = wl + (size_t)min(stream, last) * (2 * NT * 64);
-            constexpr bool dummy = false; (void)dummy;
-            const bool odd = ((PAR0 + ks) & 1) != 0;   // compile-time after unrolling
-            f16x8 (&w0)[NT] = odd ? wb0 : wa0;
-            f16x8 (&w1)[NT] = odd ? wb1 : wa1;
-            f16x8 (&w0n)[NT] = odd ? wa0 : wb0;
-            f16x8 (&w1n)[NT] = odd ? wa1 : wb1;
-            f16x8 (&x0)[4] = (ks & 1) ? xb : xa;
-            f16x8 (&x0n)[4] = (ks & 1) ? xa : xb;
-            // next K-step's weights first (L2-resident, short), then this K-step's slice of the next halo tile (HBM, long):
-            // the wait for the weights at the top of the next K-step leaves the newest slice in flight
+            if ((!(ABL & 4) || ks == 0) && !(MODE == 2 && ks == 0)) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) { w1n[nt] = wk[(1 * NT + nt) * 64]; w0n[nt] = wk[(0 * NT + nt) * 64]; }
-#pragma unroll
-            for (int m = 0; m < 4; ++m) x1[m] = *reinterpret_cast<const f16x8 *>(px + G::PLANE * 16 + m * G::TW * 32);
-            h2_stage_load<KH, KW>(plan, nxt_grp, r, ks * PER, (ks + 1) * PER);
+                for (int m = 0; m < RW; ++m) x1[m] = *reinterpret_cast<const f16x8 *>(px + G::PLANE * 16 + m * G::TW * 32);
+            }
+            if (!(ABL & 1)) h2_stage_load<KH, KW>(plan, nxt_grp, rl, ks * PER, (ks + 1) * PER);
+            const f16x8 *wf = wl + (size_t)min(stream, last) * (2 * NT * 64);   // next K-step's fragments (L2-resident)
             __builtin_amdgcn_sched_barrier(0);
-            // phase A
+            // phase A: x0*w1, then w1 is free for the next K-step's fragments
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < RW; ++m)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[nt], x0[m], acc[m][nt], 0, 0, 0);
-                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[nt], x0[m], acc[m][nt], 0, 0, 0);
-                }
-            if (ks + 1 < NK) {
-                const char *pn = xaddr(ks + 1);
+                for (int nt = 0; nt < CW; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[nt], x0[m], acc[m][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);   // keep the refill behind the MFMAs that read the old fragments (same registers)
+            if (!(ABL & 2)) {
 #pragma unroll
-                for (int m = 0; m < 4; ++m) x0n[m] = *reinterpret_cast<const f16x8 *>(pn + m * G::TW * 32);
+                for (int nt = 0; nt < CW; ++nt) w1[nt] = wf[(1 * NT + nt) * 64];
             }
             __builtin_amdgcn_sched_barrier(0);
-            // phase B
+            // phase B1: x0*w0, then x0 is free for the next K-step's pixels
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < RW; ++m)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[nt], x1[m], acc[m][nt], 0, 0, 0);
+                for (int nt = 0; nt < CW; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[nt], x0[m], acc[m][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 1 < NK && !(ABL & 4)) {
+                const char *pn = xaddr(ks + 1);
+#pragma unroll
+                for (int m = 0; m < RW; ++m) x0[m] = *reinterpret_cast<const f16x8 *>(pn + m * G::TW * 32);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // phase B2: x1*w0, then w0 is free
+#pragma unroll
+            for (int m = 0; m < RW; ++m)
+#pragma unroll
+                for (int nt = 0; nt < CW; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[nt], x1[m], acc[m][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(ABL & 2)) {
+#pragma unroll
+                for (int nt = 0; nt < CW; ++nt) w0[nt] = wf[(0 * NT + nt) * 64];
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
-        // the partner buffer is only overwritten here, after the last K-step that may read the previous group from it
-        if (more) h2_stage_store<KH, KW>(plan, lds + ((cb + 1) & 1) * G::PIECES, r);
+        // the partner halo buffer is only overwritten here, after the last K-step that may read the previous group from it
+        if (MODE == 1 && g < 2) {   // deferred last tap of the even group, carried in registers across the barrier
+            const char *pl = buf + O_LAST + pb;
+#pragma unroll
+            for (int m = 0; m < RW; ++m) {
+                x0[m] = *reinterpret_cast<const f16x8 *>(pl + m * G::TW * 32);
+                x1[m] = *reinterpret_cast<const f16x8 *>(pl + G::PLANE * 16 + m * G::TW * 32);
+            }
+        }
+        // the store goes to the buffer nobody reads during this group (the deferred tap travels in registers)
+        if (more && !(ABL & 1)) h2_stage_store<KH, KW>(plan, lds + ((cb + 1) & 1) * G::PIECES, rs);
         __syncthreads();
     };
 
-    typedef std::integral_constant<int, 0> I0;
-    typedef std::integral_constant<int, 1> I1;
-    typedef std::integral_constant<int, 2> I2;
-    if (paired) {   // K-steps per pair of groups = TAPS (odd): the weight-set parity flips from one pair to the next
-        constexpr int HP = (G::TAPS - 1) / 2;
-        typedef std::integral_constant<int, HP & 1> P1;          // parity at the start of the odd group, first pair
-        typedef std::integral_constant<int, (HP & 1) ^ 1> P1n;   // ... second pair
-        for (int cb = 0; cb < CB; cb += 4) {
-            group(I1{}, I0{}, cb);
-            group(I2{}, P1{}, cb + 1);
-            if (cb + 2 < CB) {
-                group(I1{}, I1{}, cb + 2);
-                group(I2{}, P1n{}, cb + 3);
-            }
+    if (paired) {
+        for (int cb = 0; cb < CB; cb += 2) {
+            group(std::integral_constant<int, 1>{}, cb);
+            group(std::integral_constant<int, 2>{}, cb + 1);
         }
     } else {
-        static_assert(G::NKS & 1, "plain mode assumes an odd number of K-steps per group");
-        for (int cb = 0; cb < CB; cb += 2) {
-            group(I0{}, I0{}, cb);
-            if (cb + 1 < CB) group(I0{}, I1{}, cb + 1);
-        }
+        for (int cb = 0; cb < CB; ++cb) group(std::integral_constant<int, 0>{}, cb);
     }
 }
 
-template <int KH, int KW, int NT, bool SC>
+template <int KH, int KW, int NT, bool SC, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_h2_kernel(ConvX6Args a)
 {
     typedef GeoH<KH, KW> G;
     __shared__ u32x4 lds[2 * G::PIECES];
     const int tiles_x = a.W >> 4, tiles = tiles_x * (a.H >> 4);
     const int n = blockIdx.x / tiles, t = blockIdx.x - n * tiles, ty = t / tiles_x, tx = t - ty * tiles_x;
+    typedef WaveTile<NT> WT;
+    constexpr int RW = WT::RW, CW = WT::CW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, xl = lane & 15, g = lane >> 4;
+    const int rh = wave % WT::RSPLIT, ch = wave / WT::RSPLIT;
 
-    f32x4 acc[4][NT];
+    f32x4 acc[RW][CW];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < RW; ++m)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < CW; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    h2_accumulate<KH, KW, NT>(a.x, a.x_stride, a.w, a.Cin, a.H, a.W, n, ty, tx, lds, acc);
-    if (SC) h2_accumulate<1, 1, NT>(a.x_sc, a.sc_stride, a.w_sc, a.Csc, a.H, a.W, n, ty, tx, lds, acc);
+    h2_accumulate<KH, KW, NT, ABL>(a.x, a.x_stride, a.w, a.Cin, a.H, a.W, n, ty, tx, lds, acc);
+    if (SC) h2_accumulate<1, 1, NT, 0>(a.x_sc, a.sc_stride, a.w_sc, a.Csc, a.H, a.W, n, ty, tx, lds, acc);
 
     const int H = a.H, W = a.W;
     const size_t grp = (size_t)H * W * 16;
     const float inv_scale = a.out_scale;
+    if (ABL & 8) {  // timing-only build: skip the epilogue but keep the accumulators live
+        float sacc = 0.f;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
+        for (int nt = 0; nt < CW; ++nt)
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int y = ty * 16 + wave * 4 + m, x = tx * 16 + xl;
-            const size_t off = ((size_t)n * NT + nt) * grp + ((size_t)y * W + x) * 16 + g * 4;
+            for (int m = 0; m < RW; ++m) sacc += acc[m][nt].x + acc[m][nt].y + acc[m][nt].z + acc[m][nt].w;
+        if (sacc == 123.456f) a.out[0] = 1;
+        return;
+    }
+#pragma unroll
+    for (int nt = 0; nt < CW; ++nt) {
+#pragma unroll
+        for (int m = 0; m < RW; ++m) {
+            const int y = ty * 16 + rh * RW + m, x = tx * 16 + xl;
+            const size_t off = ((size_t)n * NT + ch * CW + nt) * grp + ((size_t)y * W + x) * 16 + g * 4;
             f32x4 v = acc[m][nt] * inv_scale;   // undo the power-of-two weight scaling (exact)
             if (a.res) v += load_split2_4(a.res + off, a.res_stride);
             if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -246,24 +286,25 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(ConvX6Args a)
         }
         if (!a.pool) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int y = ty * 16 + wave * 4 + m, x = tx * 16 + xl;
-                const size_t off = ((size_t)n * NT + nt) * grp + ((size_t)y * W + x) * 16 + g * 4;
+            for (int m = 0; m < RW; ++m) {
+                const int y = ty * 16 + rh * RW + m, x = tx * 16 + xl;
+                const size_t off = ((size_t)n * NT + ch * CW + nt) * grp + ((size_t)y * W + x) * 16 + g * 4;
                 if (a.out_f32) *reinterpret_cast<f32x4 *>(a.out_f32 + off) = acc[m][nt];
+                else if ((ABL & 16) && a.N > 0) { f32x4 q = acc[m][nt]; _Float16 h0, h1; split2(q.x + q.y + q.z + q.w, h0, h1); if ((float)h0 + (float)h1 == 123.456f) a.out[off] = 1; }   // timing-only: the conversion work without the stores
                 else store_split2_4(a.out + off, a.out_stride, acc[m][nt]);
             }
         } else {
             const int Ho = H >> 1, Wo = W >> 1;
 #pragma unroll
-            for (int m = 0; m < 4; m += 2) {
+            for (int m = 0; m < RW; m += 2) {
                 f32x4 v = acc[m][nt], u = acc[m + 1][nt];
                 v.x = fmaxf(v.x, u.x); v.y = fmaxf(v.y, u.y); v.z = fmaxf(v.z, u.z); v.w = fmaxf(v.w, u.w);
                 f32x4 o;
                 o.x = __shfl_xor(v.x, 1); o.y = __shfl_xor(v.y, 1); o.z = __shfl_xor(v.z, 1); o.w = __shfl_xor(v.w, 1);
                 v.x = fmaxf(v.x, o.x); v.y = fmaxf(v.y, o.y); v.z = fmaxf(v.z, o.z); v.w = fmaxf(v.w, o.w);
                 if ((xl & 1) == 0) {
-                    const int yo = ty * 8 + wave * 2 + (m >> 1), xo = tx * 8 + (xl >> 1);
-                    const size_t off = (((size_t)n * NT + nt) * Ho + yo) * Wo * 16 + (size_t)xo * 16 + g * 4;
+                    const int yo = ty * 8 + rh * (RW / 2) + (m >> 1), xo = tx * 8 + (xl >> 1);
+                    const size_t off = (((size_t)n * NT + ch * CW + nt) * Ho + yo) * Wo * 16 + (size_t)xo * 16 + g * 4;
                     if (a.out_f32) *reinterpret_cast<f32x4 *>(a.out_f32 + off) = v;
                     else store_split2_4(a.out + off, a.out_stride, v);
                 }
@@ -283,15 +324,32 @@ static hipError_t launch_h2(hipStream_t s, const ConvX6Args &a)
     switch (a.Cout >> 4) {
     case 1: PMP_H2_LAUNCH(1); break;
     case 2: PMP_H2_LAUNCH(2); break;
-    case 4: PMP_H2_LAUNCH(4); break;
+    case 4:
+        if (KH == 3 && !a.x_sc && g_conv_variant >= 10) {   // timing-only ablation builds
+            switch (g_conv_variant - 10) {
+            case 1: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 1>), dim3(grid), dim3(256), 0, s, a); break;
+            case 2: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 2>), dim3(grid), dim3(256), 0, s, a); break;
+            case 4: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 4>), dim3(grid), dim3(256), 0, s, a); break;
+            case 8: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 8>), dim3(grid), dim3(256), 0, s, a); break;
+            case 9: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 9>), dim3(grid), dim3(256), 0, s, a); break;
+            case 15: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 15>), dim3(grid), dim3(256), 0, s, a); break;
+            case 16: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 16>), dim3(grid), dim3(256), 0, s, a); break;
+            default: PMP_H2_LAUNCH(4); break;
+            }
+        } else {
+            PMP_H2_LAUNCH(4);
+        }
+        break;
     default: return hipErrorInvalidValue;
     }
 #undef PMP_H2_LAUNCH
     return hipGetLastError();
 }
 
-hipError_t launch_conv_h2(hipStream_t s, const ConvX6Args &a)
+hipError_t launch_conv_h2(hipStream_t s, const ConvX6Args &a_in)
 {
+    const ConvX6Args &a = a_in;
+
     if ((a.H & 15) || (a.W & 15) || (a.Cin & 15) || (a.Cout & 15) || (a.x_sc && (a.Csc & 15)) || a.N <= 0)
         return hipErrorInvalidValue;
     if (a.pool && a.gate) return hipErrorInvalidValue;

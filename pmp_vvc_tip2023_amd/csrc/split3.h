@@ -77,6 +77,16 @@ __device__ __forceinline__ void store_split2_4(unsigned short *p, size_t plane_s
     *reinterpret_cast<f16x4 *>(p + plane_stride) = b;
 }
 
+// same, with the streaming (non-temporal) hint: activations are written once and read by the NEXT launch, far beyond L2
+__device__ __forceinline__ void store_split2_4_nt(unsigned short *p, size_t plane_stride, f32x4 v)
+{
+    _Float16 a0, a1, a2, a3, b0, b1, b2, b3;
+    split2(v.x, a0, b0); split2(v.y, a1, b1); split2(v.z, a2, b2); split2(v.w, a3, b3);
+    const f16x4 a = {a0, a1, a2, a3}, b = {b0, b1, b2, b3};
+    __builtin_nontemporal_store(a, reinterpret_cast<f16x4 *>(p));
+    __builtin_nontemporal_store(b, reinterpret_cast<f16x4 *>(p + plane_stride));
+}
+
 // Activation formats: 0 = plain fp32, 1 = split-3 (three bf16 planes), 2 = split-2 (two fp16 planes).
 enum { FMT_F32 = 0, FMT_B3 = 1, FMT_H2 = 2 };
 

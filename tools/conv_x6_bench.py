@@ -11,8 +11,11 @@ shapes = [(256, 64, 64, 64, 64, 3), (256, 64, 64, 64, 64, 5), (256, 64, 64, 32, 
 abl = [0]
 if len(sys.argv) > 1 and sys.argv[1] == "ablate":
     shapes = [(256, 64, 64, 64, 64, 3)]
+    if split == "f16x3": sys.argv[1] = "ablate_h2"
     abl = [0, 1, 2, 4, 8, 16, 32, 200, 128]      # bits: 1 staging, 2 weight loads, 4 x reads, 8 epilogue, 16 barrier, 32 staging from L2-resident addresses, 200 = LDS stores only, 128 = stamps
-elif len(sys.argv) > 1:
+if len(sys.argv) > 1 and sys.argv[1] == "ablate_h2":
+    abl = [0, 1, 2, 4, 8, 16, 9, 15]   # 16: epilogue without its stores (and a quarter of the conversions)
+elif len(sys.argv) > 1 and sys.argv[1] != "ablate":
     shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
 for ab in abl:
   eng.lib.pmp_debug_set_conv_variant(10 + ab if ab else 2)
