@@ -132,16 +132,19 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
     constexpr int O_LAST = (((G::TAPS - 1) / KW) * G::TW + (G::TAPS - 1) % KW) * 32;   // byte offset of the last tap
     f16x8 x0[RW], x1[RW];   // pixel fragments of the current K-step (split 0 / split 1)
 
-    auto group = [&](auto mode_tag, int cb) {
+    auto group = [&](auto mode_tag, auto tail_tag, int cb) {
         constexpr int MODE = decltype(mode_tag)::value;
+        constexpr int TAIL = decltype(tail_tag)::value;     // 2: last channel group of the pass, 1: the one before, 0: any other
+        constexpr bool LAST = TAIL == 2;
         constexpr int NK = MODE == 0 ? G::NKS : (MODE == 1 ? (G::TAPS - 1) / 2 : (G::TAPS - 1) / 2 + 1);
         constexpr int PER = (G::NLD + (NK > 0 ? NK : 1) - 1) / (NK > 0 ? NK : 1);   // staging loads issued per K-step
         constexpr int DIST = (MODE == 0 || !DEEP) ? 1 : 2;   // groups between a halo request and its LDS store
+        constexpr bool FETCH = TAIL < (DIST == 2 ? 1 : 2);    // is there a group cb+DIST to request
         u32x4 (&rbb)[G::NLD] = reinterpret_cast<u32x4 (&)[G::NLD]>(rb);
         u32x4 (&rl)[G::NLD] = (DIST == 2 && MODE == 2) ? rbb : r;   // requested during this group
         u32x4 (&rs)[G::NLD] = (DIST == 2 && MODE == 1) ? rbb : r;   // written to LDS at the end of this group (for group cb+1)
-        const bool more = cb + 1 < CB;
-        const unsigned short *nxt_grp = grp0 + (size_t)min(cb + DIST, CB - 1) * grp_sz;   // clamped: loads stay unconditional
+        constexpr bool more = !LAST;
+        const unsigned short *nxt_grp = grp0 + (size_t)min(cb + DIST, CB - 1) * grp_sz;   // clamped (odd group in a deep pair before the tail)
         const char *buf = reinterpret_cast<const char *>(lds + (cb & 1) * G::PIECES);
         auto xaddr = [&](int ks) -> const char * {   // in-group tap pair of K-step ks
             const int j = MODE == 2 ? ks - 1 : ks;
@@ -151,7 +154,7 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
             return buf + (tapsel ? oB : oA) + pb;
         };
         if (NK == 0) {   // 1x1 source, even group: nothing to compute yet, only fetch the partner group
-            if (!(ABL & 1)) h2_stage_load<KH, KW>(plan, nxt_grp, rl);
+            if (!(ABL & 1) && FETCH) h2_stage_load<KH, KW>(plan, nxt_grp, rl);
         } else if (MODE == 2) {
             // cross-group pair: lanes g < 2 still hold the even group's last tap (picked up before the barrier that ended
             // it - that buffer is being overwritten by now), lanes g >= 2 read this group's last tap
@@ -177,7 +180,7 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
 #pragma unroll
                 for (int m = 0; m < RW; ++m) x1[m] = *reinterpret_cast<const f16x8 *>(px + G::PLANE * 16 + m * G::TW * 32);
             }
-            if (!(ABL & 1)) h2_stage_load<KH, KW>(plan, nxt_grp, rl, ks * PER, (ks + 1) * PER);
+            if (!(ABL & 1) && FETCH) h2_stage_load<KH, KW>(plan, nxt_grp, rl, ks * PER, (ks + 1) * PER);
             const f16x8 *wf = wl + (size_t)min(stream, last) * (2 * NT * 64);   // next K-step's fragments (L2-resident)
             __builtin_amdgcn_sched_barrier(0);
             // phase A: x0*w1, then w1 is free for the next K-step's fragments
@@ -229,13 +232,22 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
         __syncthreads();
     };
 
-    if (paired) {
-        for (int cb = 0; cb < CB; cb += 2) {
-            group(std::integral_constant<int, 1>{}, cb);
-            group(std::integral_constant<int, 2>{}, cb + 1);
+    typedef std::integral_constant<int, 0> M0;
+    typedef std::integral_constant<int, 1> M1;
+    typedef std::integral_constant<int, 2> M2;
+    typedef std::integral_constant<int, 0> T0;
+    typedef std::integral_constant<int, 1> T1;
+    typedef std::integral_constant<int, 2> T2;
+    if (paired) {   // the last two groups are peeled: they have nothing (or less) to request
+        for (int cb = 0; cb + 2 < CB; cb += 2) {
+            group(M1{}, T0{}, cb);
+            group(M2{}, T0{}, cb + 1);
         }
+        group(M1{}, T1{}, CB - 2);
+        group(M2{}, T2{}, CB - 1);
     } else {
-        for (int cb = 0; cb < CB; ++cb) group(std::integral_constant<int, 0>{}, cb);
+        for (int cb = 0; cb + 1 < CB; ++cb) group(M0{}, T0{}, cb);
+        group(M0{}, T2{}, CB - 1);
     }
 }
 
@@ -257,12 +269,15 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(ConvX6Args a)
 #pragma unroll
         for (int nt = 0; nt < CW; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    const int H = a.H, W = a.W;
+    const size_t grp = (size_t)H * W * 16;
     h2_accumulate<KH, KW, NT, ABL>(a.x, a.x_stride, a.w, a.Cin, a.H, a.W, n, ty, tx, lds, acc);
     if (SC) h2_accumulate<1, 1, NT, 0>(a.x_sc, a.sc_stride, a.w_sc, a.Csc, a.H, a.W, n, ty, tx, lds, acc);
 
-    const int H = a.H, W = a.W;
-    const size_t grp = (size_t)H * W * 16;
     const float inv_scale = a.out_scale;
+    // element offset of (row 0, cout group 0) of this wave inside a [n][NT][H][W][16] tensor: < 2^32 for every chunk size
+    const unsigned off0 = (unsigned)(((size_t)n * NT + ch * CW) * grp + ((size_t)(ty * 16 + rh * RW) * W + tx * 16 + xl) * 16 + g * 4);
+    const unsigned row_el = (unsigned)W * 16;
     if (ABL & 8) {  // timing-only build: skip the epilogue but keep the accumulators live
         float sacc = 0.f;
 #pragma unroll
@@ -272,14 +287,39 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(ConvX6Args a)
         if (sacc == 123.456f) a.out[0] = 1;
         return;
     }
+    // All residual (then gate) fragments are requested before the first store: the weight, pixel and staging registers are
+    // dead by now, and a load issued after a store to `out` would otherwise have to wait for it (possible aliasing).
+    if (a.res) {
+        f16x4 ra[RW][CW], rbv[RW][CW];
+#pragma unroll
+        for (int nt = 0; nt < CW; ++nt)
+#pragma unroll
+            for (int m = 0; m < RW; ++m) {
+                const unsigned off = off0 + (unsigned)m * row_el + (unsigned)nt * (unsigned)grp;
+                ra[m][nt] = *reinterpret_cast<const f16x4 *>(a.res + off);
+                rbv[m][nt] = *reinterpret_cast<const f16x4 *>(a.res + off + a.res_stride);
+            }
+#pragma unroll
+        for (int nt = 0; nt < CW; ++nt)
+#pragma unroll
+            for (int m = 0; m < RW; ++m) {
+                f32x4 v = acc[m][nt] * inv_scale;   // undo the power-of-two weight scaling (exact)
+                const f16x4 p = ra[m][nt], q = rbv[m][nt];
+                v.x += (float)p.x + (float)q.x; v.y += (float)p.y + (float)q.y; v.z += (float)p.z + (float)q.z; v.w += (float)p.w + (float)q.w;
+                acc[m][nt] = v;
+            }
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < CW; ++nt)
+#pragma unroll
+            for (int m = 0; m < RW; ++m) acc[m][nt] = acc[m][nt] * inv_scale;
+    }
 #pragma unroll
     for (int nt = 0; nt < CW; ++nt) {
 #pragma unroll
         for (int m = 0; m < RW; ++m) {
-            const int y = ty * 16 + rh * RW + m, x = tx * 16 + xl;
-            const size_t off = ((size_t)n * NT + ch * CW + nt) * grp + ((size_t)y * W + x) * 16 + g * 4;
-            f32x4 v = acc[m][nt] * inv_scale;   // undo the power-of-two weight scaling (exact)
-            if (a.res) v += load_split2_4(a.res + off, a.res_stride);
+            const unsigned off = off0 + (unsigned)m * row_el + (unsigned)nt * (unsigned)grp;
+            f32x4 v = acc[m][nt];
             if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             if (a.gate) v *= load_split2_4(a.gate + off, a.gate_stride);
             acc[m][nt] = v;
@@ -287,8 +327,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(ConvX6Args a)
         if (!a.pool) {
 #pragma unroll
             for (int m = 0; m < RW; ++m) {
-                const int y = ty * 16 + rh * RW + m, x = tx * 16 + xl;
-                const size_t off = ((size_t)n * NT + ch * CW + nt) * grp + ((size_t)y * W + x) * 16 + g * 4;
+                const unsigned off = off0 + (unsigned)m * row_el + (unsigned)nt * (unsigned)grp;
                 if (a.out_f32) *reinterpret_cast<f32x4 *>(a.out_f32 + off) = acc[m][nt];
                 else if ((ABL & 16) && a.N > 0) { f32x4 q = acc[m][nt]; _Float16 h0, h1; split2(q.x + q.y + q.z + q.w, h0, h1); if ((float)h0 + (float)h1 == 123.456f) a.out[off] = 1; }   // timing-only: the conversion work without the stores
                 else store_split2_4(a.out + off, a.out_stride, acc[m][nt]);
