@@ -214,7 +214,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "CTUs/sec (luma QT+MTT inference+post-proc)", "value": round(blocks_per_s / 4.0, 2), "unit": "CTU/s",
+            "metric": "CTUs/sec (%s QT+MTT inference+post-proc)" % args.comp.lower(), "value": round(blocks_per_s / 4.0, 2), "unit": "CTU/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else args.precision, "data": "synthetic",

@@ -180,7 +180,13 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
 #pragma unroll
                 for (int m = 0; m < RW; ++m) x1[m] = *reinterpret_cast<const f16x8 *>(px + G::PLANE * 16 + m * G::TW * 32);
             }
-            if (!(ABL & 1) && FETCH) h2_stage_load<KH, KW>(plan, nxt_grp, rl, ks * PER, (ks + 1) * PER);
+            // All of the group's halo requests go out with its first K-step: the counter that orders vector-memory
+            // operations is in-order, so a weight fragment requested after an HBM load cannot be used before that load has
+            // landed - one such wait per group instead of one per K-step.
+            if (!(ABL & 1) && FETCH) {
+                if (ABL & 32) { if (ks == 0) h2_stage_load<KH, KW>(plan, nxt_grp, rl); }
+                else h2_stage_load<KH, KW>(plan, nxt_grp, rl, ks * PER, (ks + 1) * PER);
+            }
             const f16x8 *wf = wl + (size_t)min(stream, last) * (2 * NT * 64);   // next K-step's fragments (L2-resident)
             __builtin_amdgcn_sched_barrier(0);
             // phase A: x0*w1, then w1 is free for the next K-step's fragments
@@ -373,6 +379,7 @@ static hipError_t launch_h2(hipStream_t s, const ConvX6Args &a)
             case 9: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 9>), dim3(grid), dim3(256), 0, s, a); break;
             case 15: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 15>), dim3(grid), dim3(256), 0, s, a); break;
             case 16: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 16>), dim3(grid), dim3(256), 0, s, a); break;
+            case 32: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 32>), dim3(grid), dim3(256), 0, s, a); break;
             default: PMP_H2_LAUNCH(4); break;
             }
         } else {

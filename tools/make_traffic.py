@@ -9,7 +9,8 @@ import os
 if os.path.isfile("profiles/pmc_traffic.json"):
     out = json.load(open("profiles/pmc_traffic.json"))
 for k, v in src.items():
-    mode = "fp32" if k.startswith("conv_mfma_kernel<3, 3, 4") else ("bf16x6" if k.startswith("conv_x6_kernel<3, 3, 4") else None)
+    mode = "fp32" if k.startswith("conv_mfma_kernel<3, 3, 4") else ("bf16x6" if k.startswith("conv_x6_kernel<3, 3, 4") else
+                                                                      ("f16x3" if k.startswith("conv_h2_kernel<3, 3, 4, sc=false") else None))
     if mode and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         out["conv_mfma_3x3_c64:" + mode] = round((2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0)
         out["_detail:" + mode] = {"kernel": k, "FETCH_SIZE_KB": v["FETCH_SIZE"], "WRITE_SIZE_KB": v["WRITE_SIZE"],

@@ -35,7 +35,33 @@ def make_conv(xa, wa, pairs):
     return conv
 
 
+def split16(x, terms):
+    parts, r = [], x
+    for _ in range(terms):
+        h = r.to(torch.float16).float()     # subnormals kept, as the MFMA does (tools/probe/f16_denorm.hip)
+        parts.append(h)
+        r = r - h
+    return parts
+
+
+def make_conv_f16(scale, pairs):
+    """Two-term fp16 split of x and of scale*w; the result is divided by scale (a power of two: exact)."""
+    def conv(x, w, b, pad):
+        xs, ws = split16(x, 2), split16(w * scale, 2)
+        out = None
+        for (i, j) in pairs:
+            t = F.conv2d(xs[i], ws[j], None, padding=pad)
+            out = t if out is None else out + t
+        out = out / scale
+        if b is not None:
+            out = out + b.view(1, -1, 1, 1)
+        return out
+    return conv
+
+
 MODES = {
+    "f16x3 unscaled": make_conv_f16(1.0, [(0, 1), (1, 0), (0, 0)]),
+    "f16x3 weights x256": make_conv_f16(256.0, [(0, 1), (1, 0), (0, 0)]),
     "bf16x1": make_conv(1, 1, [(0, 0)]),
     "bf16x3 (hh,hl,lh)": make_conv(2, 2, [(1, 0), (0, 1), (0, 0)]),
     "bf16x4 (+ll)": make_conv(2, 2, [(1, 1), (1, 0), (0, 1), (0, 0)]),

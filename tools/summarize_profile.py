@@ -15,6 +15,9 @@ def short(name):
     m = re.search(r"(conv_x6_kernel)<(\d+), ?(\d+), ?(\d+)", name)
     if m:
         return "conv_x6_kernel<%s, %s, %s>" % m.groups()[1:]
+    m = re.search(r"(conv_h2_kernel)<(\d+), ?(\d+), ?(\d+), ?(\w+)", name)
+    if m:
+        return "conv_h2_kernel<%s, %s, %s, sc=%s>" % m.groups()[1:]
     name = name.replace("void ", "").replace("pmp::", "").replace("(anonymous namespace)::", "")
     return name[:70]
 
