@@ -26,6 +26,17 @@
 
 namespace pmp {
 
+// In-kernel stamps (diagnostic build only, ABL bit 128): shader-clock ticks of wave 0 at phase boundaries, written to a debug
+// buffer nothing else reads.
+__device__ __forceinline__ unsigned long long h2_stamp()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+
 template <int KH, int KW>
 struct GeoH {
     static constexpr int TH = 16 + KH - 1, TW = 16 + KW - 1, TAPS = KH * KW, NKS = (TAPS + 1) / 2;
@@ -95,8 +106,10 @@ struct WaveTile {
 template <int KH, int KW, int NT, int ABL = 0>
 __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__ x, size_t plane_stride,
                                               const unsigned short *__restrict__ wpk, int C, int H, int W, int n, int ty,
-                                              int tx, u32x4 *lds, f32x4 (&acc)[WaveTile<NT>::RW][WaveTile<NT>::CW])
+                                              int tx, u32x4 *lds, f32x4 (&acc)[WaveTile<NT>::RW][WaveTile<NT>::CW], unsigned long long *dbg = nullptr)
 {
+    unsigned long long t_pro = 0, t_k = 0, t_s = 0, t_b = 0, tmark = 0;   // diagnostic accumulators (ABL & 128)
+    if (ABL & 128) tmark = h2_stamp();
     typedef GeoH<KH, KW> G;
     typedef WaveTile<NT> WT;
     constexpr int RW = WT::RW, CW = WT::CW;
@@ -125,6 +138,7 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
     if (DEEP && paired) h2_stage_load<KH, KW>(plan, grp0 + grp_sz, reinterpret_cast<u32x4 (&)[G::NLD]>(rb));   // group 1 exists: CB is even
     h2_stage_store<KH, KW>(plan, lds, r);
     __syncthreads();
+    if (ABL & 128) { const unsigned long long t = h2_stamp(); t_pro = t - tmark; tmark = t; }
     // ABL: timing-only builds (tools/conv_x6_bench.py h2 ablate): 1 no halo staging, 2 no weight refills, 4 no fragment reads, 8 no epilogue
     const int pb = ((rh * RW * G::TW + xl) * 2 + (g & 1)) * 16;   // bytes inside a split plane, tap (0,0)
     int stream = 0;
@@ -233,9 +247,12 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
                 x1[m] = *reinterpret_cast<const f16x8 *>(pl + G::PLANE * 16 + m * G::TW * 32);
             }
         }
+        if (ABL & 128) { const unsigned long long t = h2_stamp(); t_k += t - tmark; tmark = t; }
         // the store goes to the buffer nobody reads during this group (the deferred tap travels in registers)
         if (more && !(ABL & 1)) h2_stage_store<KH, KW>(plan, lds + ((cb + 1) & 1) * G::PIECES, rs);
+        if (ABL & 128) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t = h2_stamp(); t_s += t - tmark; tmark = t; }
         __syncthreads();
+        if (ABL & 128) { const unsigned long long t = h2_stamp(); t_b += t - tmark; tmark = t; }
     };
 
     typedef std::integral_constant<int, 0> M0;
@@ -255,6 +272,7 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
         for (int cb = 0; cb + 1 < CB; ++cb) group(M0{}, T0{}, cb);
         group(M0{}, T2{}, CB - 1);
     }
+    if ((ABL & 128) && dbg && threadIdx.x == 0) { dbg[0] = t_pro; dbg[1] = t_k; dbg[2] = t_s; dbg[3] = t_b; }
 }
 
 template <int KH, int KW, int NT, bool SC, int ABL = 0>
@@ -277,7 +295,9 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(ConvX6Args a)
 
     const int H = a.H, W = a.W;
     const size_t grp = (size_t)H * W * 16;
-    h2_accumulate<KH, KW, NT, ABL>(a.x, a.x_stride, a.w, a.Cin, a.H, a.W, n, ty, tx, lds, acc);
+    const unsigned long long t_begin = (ABL & 128) ? h2_stamp() : 0;
+    h2_accumulate<KH, KW, NT, ABL>(a.x, a.x_stride, a.w, a.Cin, a.H, a.W, n, ty, tx, lds, acc, a.dbg ? a.dbg + (size_t)blockIdx.x * 8 : nullptr);
+    const unsigned long long t_acc = (ABL & 128) ? h2_stamp() : 0;
     if (SC) h2_accumulate<1, 1, NT, 0>(a.x_sc, a.sc_stride, a.w_sc, a.Csc, a.H, a.W, n, ty, tx, lds, acc);
 
     const float inv_scale = a.out_scale;
@@ -356,6 +376,12 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(ConvX6Args a)
             }
         }
     }
+    if ((ABL & 128) && a.dbg && threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // include the store acknowledgements in the epilogue span
+        const unsigned long long t_end = h2_stamp();
+        unsigned long long *d = a.dbg + (size_t)blockIdx.x * 8;
+        d[4] = t_acc - t_begin; d[5] = t_end - t_acc; d[6] = t_begin; d[7] = t_end;
+    }
 }
 
 template <int KH, int KW>
@@ -380,6 +406,7 @@ static hipError_t launch_h2(hipStream_t s, const ConvX6Args &a)
             case 15: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 15>), dim3(grid), dim3(256), 0, s, a); break;
             case 16: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 16>), dim3(grid), dim3(256), 0, s, a); break;
             case 32: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 32>), dim3(grid), dim3(256), 0, s, a); break;
+            case 128: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 128>), dim3(grid), dim3(256), 0, s, a); break;
             default: PMP_H2_LAUNCH(4); break;
             }
         } else {

@@ -1,4 +1,5 @@
 // pmp_api.cpp — the C ABI declared in include/pmp.h.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -578,6 +579,30 @@ int pmp_debug_conv_bench(pmp_ctx *c, int n, int h, int w, int cin, int cout, int
                 fprintf(stderr, "stamps (mean ticks per workgroup, wave 0): prologue %.0f | K-steps %.0f | wait for staged loads %.0f | "
                                 "LDS store %.0f | barrier %.0f | accumulate total %.0f | epilogue incl. store ack %.0f\n",
                         s[0] / wgs, s[1] / wgs, s[6] / wgs, s[2] / wgs, s[7] / wgs, s[3] / wgs, s[4] / wgs);
+                b.dbg = nullptr;
+                hipFree(ddbg);
+            }
+        }
+        if (h2 && g_conv_variant == 10 + 128 && k == 3 && cout == 64) {   // in-kernel stamp report (diagnostic build)
+            const int wgs = n * (h / 16) * (w / 16);
+            unsigned long long *ddbg = nullptr;
+            if (hipMalloc((void **)&ddbg, (size_t)wgs * 8 * 8) == hipSuccess) {
+                hipMemset(ddbg, 0, (size_t)wgs * 8 * 8);
+                b.dbg = ddbg;
+                launch_split();
+                hipStreamSynchronize(c->stream);
+                std::vector<unsigned long long> hd((size_t)wgs * 8);
+                hipMemcpy(hd.data(), ddbg, hd.size() * 8, hipMemcpyDeviceToHost);
+                double s[6] = {0, 0, 0, 0, 0, 0};
+                unsigned long long tmin = ~0ull, tmax = 0;
+                for (int i = 0; i < wgs; ++i) {
+                    for (int j = 0; j < 6; ++j) s[j] += (double)hd[(size_t)i * 8 + j];
+                    tmin = std::min(tmin, hd[(size_t)i * 8 + 6]);
+                    tmax = std::max(tmax, hd[(size_t)i * 8 + 7]);
+                }
+                fprintf(stderr, "f16x3 stamps (mean ticks per workgroup, wave 0): prologue %.0f | K-steps %.0f | halo LDS store incl. its wait %.0f | "
+                                "group barrier %.0f | accumulate total %.0f | epilogue incl. store ack %.0f | kernel span %.0f ticks, %d workgroups\n",
+                        s[0] / wgs, s[1] / wgs, s[2] / wgs, s[3] / wgs, s[4] / wgs, s[5] / wgs, (double)(tmax - tmin), wgs);
                 b.dbg = nullptr;
                 hipFree(ddbg);
             }
