@@ -149,9 +149,16 @@ int pmp_ktime_get(pmp_ctx *ctx, int cls, int64_t *launches, double *ms, double *
  *      Every variant computes bit-identical results; tools/conv_ab.py uses this for in-process A/B timing. ---- */
 int pmp_debug_set_conv_variant(int variant);
 
+/* ---- test hook (host only, no GPU needed): the f16x3 weight packing of one OIHW conv tensor (conv_f16x3.hip).
+ *      Writes the power-of-two exponent k of the scale S = 2^k to *scale_exp and, if out != NULL, the packed stream
+ *      [K-step][2 splits][cout_pad/16][64 lanes][8] of fp16 bit patterns (h0, h1 with h0 + h1 ~= S*w) to out.
+ *      Returns the number of uint16 elements of the stream (> cap: nothing written), or a negative error. ---- */
+int64_t pmp_debug_pack_f16x3(const float *w, int cout, int cin, int k, uint16_t *out, int64_t cap, int *scale_exp);
+
 /* ---- measurement hook: one convolution layer on random data, both datapaths.  Runs conv KxK Cin->Cout (+ReLU) on
- *      n blocks of HxW with the fp32-MFMA kernel and with the bf16x6 split kernel, `iters` timed launches each.
- *      Outputs: average milliseconds per launch and max |fp32 - bf16x6| / max |fp32| over the whole output. ---- */
+ *      n blocks of HxW with the fp32-MFMA kernel and with the context's split kernel (f16x3 or bf16x6; bf16x6 if the
+ *      context is in fp32 mode), `iters` timed launches each.
+ *      Outputs: average milliseconds per launch and max |fp32 - split| / max |fp32| over the whole output. ---- */
 int pmp_debug_conv_bench(pmp_ctx *ctx, int n, int h, int w, int cin, int cout, int k, int iters, double *ms_f32,
                          double *ms_x6, double *max_abs_diff, double *max_abs_ref);
 

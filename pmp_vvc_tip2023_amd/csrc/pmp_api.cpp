@@ -508,6 +508,17 @@ int pmp_debug_set_conv_variant(int variant)
     return PMP_OK;
 }
 
+int64_t pmp_debug_pack_f16x3(const float *w, int cout, int cin, int k, uint16_t *out, int64_t cap, int *scale_exp)
+{
+    if (!w || cout <= 0 || cin <= 0 || (k != 1 && k != 3 && k != 5) || !scale_exp)
+        return set_err(nullptr, PMP_E_INVALID, "pmp_debug_pack_f16x3: bad arguments");
+    const int kexp = h2_scale_exp(w, (size_t)cout * cin * k * k);
+    *scale_exp = kexp;
+    const std::vector<unsigned short> v = pack_h2(w, cout, cin, k, k, (cout + 15) & ~15, (cin + 15) & ~15, kexp);
+    if (out && (int64_t)v.size() <= cap) memcpy(out, v.data(), v.size() * sizeof(unsigned short));
+    return (int64_t)v.size();
+}
+
 int pmp_debug_conv_bench(pmp_ctx *c, int n, int h, int w, int cin, int cout, int k, int iters, double *ms_f32, double *ms_x6,
                          double *max_abs_diff, double *max_abs_ref)
 {

@@ -97,3 +97,65 @@ def test_binary_side_channel_equals_text(lib, comp, tmp_path, oracle_lib):
     th, tv, tq, td = engine.read_partition_file(golden_path("g5_partitionmat_%s.txt" % comp), F, H, W)
     assert np.array_equal(bh, th) and np.array_equal(bv, tv) and np.array_equal(bq, tq) and np.array_equal(bd, td)
     assert os.path.getsize(pb) == 40 + F * (5 * 16 * 32 + 8 * 16)
+
+
+@pytest.mark.parametrize("cout,cin,k", [(64, 64, 3), (32, 17, 5), (8, 32, 1), (64, 32, 5)])
+def test_f16x3_weight_packing_is_exact_to_22_bits(lib, cout, cin, k):
+    """conv_f16x3.hip's weight stream (host code, no GPU): S = 2^k puts max|S*w| in [4096, 8192); every weight is
+    h0 + h1 (two fp16 terms) to 2^-21 of its own magnitude (|w| >= 2^-16 of the largest: both terms normal), padded
+    positions are zero, and every real weight appears exactly once per K-step slot the kernel reads."""
+    import ctypes as C
+    rng = np.random.default_rng(cout * 100 + cin + k)
+    w = (rng.standard_normal((cout, cin, k, k)) * 0.05).astype(np.float32)
+    w[0, 0, 0, 0] = 0.0
+    w[1 % cout, 0, 0, 0] = np.float32(1e-7)           # far below 2^-16 of the max: may lose bits, must stay tiny
+    kexp = C.c_int(-1)
+    n = lib.pmp_debug_pack_f16x3(w.ctypes.data_as(C.POINTER(C.c_float)), cout, cin, k, None, 0, C.byref(kexp))
+    assert n > 0
+    S = 2.0 ** kexp.value
+    assert 4096.0 <= S * np.abs(w).max() < 8192.0
+    out = np.zeros(n, np.uint16)
+    assert lib.pmp_debug_pack_f16x3(w.ctypes.data_as(C.POINTER(C.c_float)), cout, cin, k, out.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                    n, C.byref(kexp)) == n
+    NT, CB, taps = (cout + 15) // 16, (cin + 15) // 16, k * k
+    paired = CB % 2 == 0 and taps % 2 == 1
+    steps = (CB // 2) * taps if paired else CB * ((taps + 1) // 2)
+    assert n == steps * 2 * NT * 64 * 8
+    st = out.view(np.float16).astype(np.float64).reshape(steps, 2, NT, 64, 8)
+    rec = (st[:, 0] + st[:, 1]) / S                     # [step][nt][lane][j]
+    # rebuild the step -> (group, tap) order of weights_pack.cpp
+    order = []
+    if paired:
+        for cb in range(CB):
+            if cb & 1:
+                order.append(((cb - 1, taps - 1), (cb, taps - 1)))
+            for ks in range((taps - 1) // 2):
+                order.append(((cb, 2 * ks), (cb, 2 * ks + 1)))
+    else:
+        for cb in range(CB):
+            for ks in range((taps + 1) // 2):
+                order.append(((cb, 2 * ks), (cb, 2 * ks + 1)))
+    assert len(order) == steps
+    wf = w.reshape(cout, cin, taps).astype(np.float64)
+    seen = np.zeros((cout, cin, taps), np.int32)
+    worst = 0.0
+    for s, halves in enumerate(order):
+        for nt in range(NT):
+            for lane in range(64):
+                g = lane >> 4
+                cb, tap = halves[g >> 1]
+                co = nt * 16 + (lane & 15)
+                for j in range(8):
+                    ci = cb * 16 + 8 * (g & 1) + j
+                    v = rec[s, nt, lane, j]
+                    if co < cout and ci < cin and tap < taps:
+                        ref = wf[co, ci, tap]
+                        seen[co, ci, tap] += 1
+                        if abs(ref) >= np.abs(w).max() * 2.0 ** -16:
+                            worst = max(worst, abs(v - ref) / abs(ref))
+                        else:
+                            assert abs(v - ref) <= 2.0 ** -24 / S * 4
+                    else:
+                        assert v == 0.0
+    assert (seen == 1).all()
+    assert worst <= 2.0 ** -21

@@ -103,6 +103,27 @@ def test_caller_supplied_weights_and_errors(eng, g1):
         e2.close()
 
 
+def test_f16x3_saturates_instead_of_overflowing(g1):
+    """f16x3 carries activations as two fp16 terms: values beyond +-65504 must saturate when split, never turn into inf/NaN
+    (include/pmp.h, PMP_PRECISION_F16X3).  A stem scaled by 1e3 drives the trunk far beyond that range."""
+    from pmp_vvc_tip2023_amd import engine, synth
+    e2 = engine.Engine(0)
+    try:
+        e2.set_precision("f16x3")
+        e2.load("Luma", 22)                                 # real QT net for the MTT net's second input
+        w = dict(synth.synth_msbd_weights("Luma", 22))
+        for k in ("conv_b1_1.weight", "conv_b1_2.weight", "conv_b1_3.weight"):
+            w[k] = (w[k] * 1e3).astype(np.float32)
+        e2.load_pretrain_model("Luma_MSBD", 22, w)
+        qt, bt, dire = e2.inference_pre_QBD("Luma", 22, g1["block_y"][:4])
+        assert np.isfinite(qt).all() and np.isfinite(bt).all() and np.isfinite(dire).all()
+        e2.set_precision("fp32")                            # the exact path agrees that the values are huge, not broken
+        _, bt32, _ = e2.inference_pre_QBD("Luma", 22, g1["block_y"][:4])
+        assert np.isfinite(bt32).all() and np.abs(bt32).max() > 1e3
+    finally:
+        e2.close()
+
+
 # ------------------------------------------------------------------------------------------------ post-processing
 def test_map_to_partition_bit_exact_vs_reference_golden(eng, oracle_lib):
     """G3 through pmp_postprocess.  The ABI applies eli_structual_error first (as seq_post_process does), so golden
