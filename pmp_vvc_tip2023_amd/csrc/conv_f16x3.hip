@@ -38,14 +38,6 @@ __device__ __forceinline__ unsigned long long h2_stamp()
 }
 
 template <int KH, int KW>
-struct GeoH {
-    static constexpr int TH = 16 + KH - 1, TW = 16 + KW - 1, TAPS = KH * KW, NKS = (TAPS + 1) / 2;
-    static constexpr int PLANE = TH * TW * 2;            // 16-B pieces per split plane (32 B per pixel)
-    static constexpr int PIECES = 2 * PLANE;             // per buffer
-    static constexpr int NLD = (PIECES + 255) / 256;
-};
-
-template <int KH, int KW>
 struct StagePlanH {
     unsigned off[GeoH<KH, KW>::NLD];
     unsigned valid;
@@ -92,16 +84,6 @@ __device__ __forceinline__ void h2_stage_store(const StagePlanH<KH, KW> &p, u32x
         if (i < G::PIECES) lds[i] = ((p.valid >> k) & 1u) ? r[k] : z;   // LDS image: [split][pixel][2 halves], linear
     }
 }
-
-// Wave tile: RW rows x CW cout groups of the workgroup's 16 rows x NT groups (4 waves).  At Cout >= 32 a wave takes 8 rows
-// and half (or all) of the cout groups: it then streams half of the weight bytes per MFMA from L2 - the vector-memory
-// path is the contended one here - and reads twice the pixel fragments from LDS, which has the headroom.
-template <int NT>
-struct WaveTile {
-    static constexpr int RW = NT >= 2 ? 8 : 4;        // rows per wave
-    static constexpr int CW = NT * RW >= 16 ? NT * RW / 16 : 1;   // cout groups per wave
-    static constexpr int RSPLIT = 16 / RW;            // waves along the rows
-};
 
 template <int KH, int KW, int NT, int ABL = 0>
 __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__ x, size_t plane_stride,

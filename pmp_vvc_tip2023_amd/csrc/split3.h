@@ -87,6 +87,31 @@ __device__ __forceinline__ void store_split2_4_nt(unsigned short *p, size_t plan
     __builtin_nontemporal_store(b, reinterpret_cast<f16x4 *>(p + plane_stride));
 }
 
+// ---- geometry shared by conv_f16x3.hip and conv_f16x3_ws.hip
+template <int KH, int KW, int TR = 16>   // TR = output rows per workgroup tile (16 columns always)
+struct GeoH {
+    static constexpr int TH = TR + KH - 1, TW = 16 + KW - 1, TAPS = KH * KW, NKS = (TAPS + 1) / 2;
+    static constexpr int PLANE = TH * TW * 2;            // 16-B pieces per split plane (32 B per pixel)
+    static constexpr int PIECES = 2 * PLANE;             // per buffer
+    static constexpr int NLD = (PIECES + 255) / 256;
+};
+
+// Wave tile: RW rows x CW cout groups of the workgroup's 16 rows x NT groups (4 waves).  At Cout >= 32 a wave takes 8 rows
+// and half (or all) of the cout groups: it then streams half of the weight bytes per MFMA from L2 - the vector-memory
+// path is the contended one here - and reads twice the pixel fragments from LDS, which has the headroom.
+template <int NT>
+struct WaveTile {
+    static constexpr int RW = NT >= 2 ? 8 : 4;        // rows per wave
+    static constexpr int CW = NT * RW >= 16 ? NT * RW / 16 : 1;   // cout groups per wave
+    static constexpr int RSPLIT = 16 / RW;            // waves along the rows
+};
+
+// s_barrier after an LDS-only wait: global loads (weights, halo requests) stay in flight across it
+__device__ __forceinline__ void h2_lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Activation formats: 0 = plain fp32, 1 = split-3 (three bf16 planes), 2 = split-2 (two fp16 planes).
 enum { FMT_F32 = 0, FMT_B3 = 1, FMT_H2 = 2 };
 
