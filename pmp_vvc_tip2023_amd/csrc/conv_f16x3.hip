@@ -103,7 +103,9 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
     // Halo staging registers.  With tap pairing (even group count) there are TWO sets: group g+2 is requested during group
     // g and written to LDS at the end of group g+1, so an HBM round trip has two groups of MFMAs to hide behind (loaded
     // latency here is longer than one 3x3 group).  Plain mode keeps one set and a distance of one group.
-    constexpr bool DEEP = G::TAPS <= 9;   // 5x5 groups (12.5 K-steps) outlast the HBM latency on their own
+    // 5x5 groups (12.5 K-steps) outlast the HBM latency on their own; the Cout <= 32 kernels are latency-bound small layers
+    // that gain more from a third resident workgroup (168 VGPRs) than from the second staging set
+    constexpr bool DEEP = G::TAPS <= 9 && NT == 4;
     u32x4 r[G::NLD], rb[DEEP ? G::NLD : 1];
     StagePlanH<KH, KW> plan;
     h2_plan<KH, KW>(plan, plane_stride, H, W, ty, tx);
@@ -258,7 +260,7 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
 }
 
 template <int KH, int KW, int NT, bool SC, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void conv_h2_kernel(ConvX6Args a)
+__global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv_h2_kernel(ConvX6Args a)
 {
     typedef GeoH<KH, KW> G;
     __shared__ u32x4 lds[2 * G::PIECES];

@@ -101,9 +101,9 @@ struct GeoH {
 // path is the contended one here - and reads twice the pixel fragments from LDS, which has the headroom.
 template <int NT>
 struct WaveTile {
-    static constexpr int RW = NT >= 2 ? 8 : 4;        // rows per wave
-    static constexpr int CW = NT * RW >= 16 ? NT * RW / 16 : 1;   // cout groups per wave
+    static constexpr int RW = NT == 4 ? 8 : 4;        // rows per wave (Cout <= 32: 4 rows - fewer registers, a third workgroup per CU)
     static constexpr int RSPLIT = 16 / RW;            // waves along the rows
+    static constexpr int CW = NT / (4 / RSPLIT);      // cout groups per wave (4 waves = RSPLIT x NT/CW)
 };
 
 // s_barrier after an LDS-only wait: global loads (weights, halo requests) stay in flight across it
