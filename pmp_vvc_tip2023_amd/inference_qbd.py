@@ -17,6 +17,8 @@ the reference hard-codes them:
   sequence file stem: the reference's rstrip(".yuv") strips a character SET (:166); a real suffix strip is used
   (identical for every name in VVC_Test_Sequences.txt and what EncAppCfg.cpp:4235-4242 expects).
   Nets are loaded once per (component, QP) instead of once per sequence (:208-224).
+  Frames are uploaded once per sequence and cut on the GPU; the blocks stay device-resident for all passes (--hostBlocks
+  restores the reference's host-side block arrays).
 """
 import argparse
 import os
@@ -107,7 +109,48 @@ def build_parser():
     p.add_argument("--comps", default="Luma,Chroma")
     p.add_argument("--device", default=None, type=int, help="GPU index (default: LOCAL_RANK)")
     p.add_argument("--binary", action="store_true", help="also write <name>_PartitionMat.pmpb (binary side channel, include/pmp.h)")
+    p.add_argument("--hostBlocks", action="store_true",
+                   help="keep the cut blocks in host memory and upload them for every (component, QP) pass, as the reference "
+                        "does; default: frames are uploaded once, cut on the GPU and the blocks stay device-resident")
     return p
+
+
+class DeviceBlocks:
+    """Device-resident blocks of one sequence shard: the sub-sampled frames are uploaded once, cut by
+    pmp_cut_blocks_device (Inference_QBD.py:104-149 on the GPU) and reused by all eight (component, QP) passes; only the split
+    flags (1344 B per block) come back.  torch is the device allocator here, nothing else."""
+
+    def __init__(self, eng, dev, y, u, v, bitdepth, lo, hi):
+        import torch
+        self.eng, self.torch, self.dev = eng, torch, dev
+        F, H, W = y.shape
+        per_frame = (H // 64) * (W // 64)
+
+        def up(a):   # torch has no uint16: 10-bit planes travel as int16 bit patterns
+            return torch.from_numpy(np.ascontiguousarray(a).view(np.int16) if a.dtype == np.uint16 else np.ascontiguousarray(a)).to(dev)
+        ty, tu, tv = up(y), up(u), up(v)
+        self.by = torch.empty((F * per_frame, 68, 68), dtype=torch.uint8, device=dev)
+        self.bu = torch.empty((F * per_frame, 34, 34), dtype=torch.uint8, device=dev)
+        self.bv = torch.empty((F * per_frame, 34, 34), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize(dev)
+        eng.cut_blocks_device(ty.data_ptr(), tu.data_ptr(), tv.data_ptr(), F, H, W, bitdepth, self.by.data_ptr(), self.bu.data_ptr(), self.bv.data_ptr())
+        eng.synchronize()
+        del ty, tu, tv
+        self.by, self.bu, self.bv = self.by[lo:hi], self.bu[lo:hi], self.bv[lo:hi]   # leading-dimension slices: still contiguous
+        self.n = hi - lo
+        self.hor = torch.empty((self.n, 16, 16), dtype=torch.uint8, device=dev)
+        self.ver = torch.empty_like(self.hor)
+        self.q8 = torch.empty((self.n, 8, 8), dtype=torch.uint8, device=dev)
+        self.d8 = torch.empty((self.n, 3, 16, 16), dtype=torch.int8, device=dev)
+        torch.cuda.synchronize(dev)
+
+    def infer_postprocess(self, comp, qp):
+        chroma = comp == "Chroma"
+        self.eng.infer_postprocess_device(comp, qp, self.by.data_ptr(), self.bu.data_ptr() if chroma else None,
+                                          self.bv.data_ptr() if chroma else None, self.n, self.hor.data_ptr(), self.ver.data_ptr(),
+                                          self.q8.data_ptr(), self.d8.data_ptr())
+        self.eng.synchronize()
+        return tuple(t.cpu().numpy() for t in (self.hor, self.ver, self.q8, self.d8))
 
 
 def _emit(rec, save_path, frames, height, width, binary):
@@ -136,6 +179,15 @@ def inference_VVC_seqs(args):
         device = torch.device("cuda", dev_id)
         torch.cuda.set_device(device)
     parallel.init_process_group(device)
+
+    torch_dev = None
+    if not args.hostBlocks:
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch_dev = torch.device("cuda", dev_id)
+        except ImportError:
+            torch_dev = None
 
     save_dir = os.path.join(args.outDir, args.jobID, "PartitionMat")
     if rank == 0:
@@ -169,10 +221,16 @@ def inference_VVC_seqs(args):
         per_frame = (width // 64) * (height // 64)
         n_total = per_frame * sub_numfrm
         lo, hi = parallel.shard_bounds(n_total, rank, world)
+        dblk = None
         if hi > lo and per_frame:
             f0, f1 = lo // per_frame, (hi + per_frame - 1) // per_frame
-            by, bu, bv = eng.output_block_yuv(y[f0:f1], u[f0:f1], v[f0:f1], 10 if is10bit else 8)
-            by, bu, bv = (a[lo - f0 * per_frame:hi - f0 * per_frame] for a in (by, bu, bv))
+            if torch_dev is not None:   # frames go up once, are cut on the GPU and the blocks never leave it
+                dblk = DeviceBlocks(eng, torch_dev, y[f0:f1], u[f0:f1], v[f0:f1], 10 if is10bit else 8,
+                                    lo - f0 * per_frame, hi - f0 * per_frame)
+                by = bu = bv = None
+            else:
+                by, bu, bv = eng.output_block_yuv(y[f0:f1], u[f0:f1], v[f0:f1], 10 if is10bit else 8)
+                by, bu, bv = (a[lo - f0 * per_frame:hi - f0 * per_frame] for a in (by, bu, bv))
         else:
             by = np.zeros((0, 68, 68), np.uint8); bu = np.zeros((0, 34, 34), np.uint8); bv = np.zeros((0, 34, 34), np.uint8)
         seqs_block_time[si] = time.time() - t0
@@ -181,7 +239,7 @@ def inference_VVC_seqs(args):
             for qp in qps:
                 qi = (qp - 22) // 5 if qp in QPS else 0
                 t0 = time.time()
-                hor, ver, q8, d8 = eng.infer_postprocess(comp, qp, by, bu, bv)
+                hor, ver, q8, d8 = dblk.infer_postprocess(comp, qp) if dblk is not None else eng.infer_postprocess(comp, qp, by, bu, bv)
                 seqs_net_time[si, qi, comp_id] = time.time() - t0
                 t0 = time.time()
                 rec = parallel.gather_records(parallel.pack_records(hor, ver, q8, d8), n_total, device)

@@ -289,6 +289,14 @@ def test_driver_end_to_end_files(eng, oracle_lib, tmp_path):
                 assert open(got, "rb").read() == open(po, "rb").read(), (name, comp, qp)
     rows = open(out / "j1" / "Time_Sta_0_2.txt").read().strip().split("\n")
     assert len(rows) == 2 * 4 and all(r.count(",") == 5 for r in rows)
+    # the default run kept the blocks device-resident; the reference-style host block arrays give the same bytes
+    out2 = tmp_path / "out_host"
+    D.main(["--jobID", "j1", "--inputDir", str(inp), "--outDir", str(out2), "--seqTable", "table.txt", "--cfgDir", str(cfg),
+            "--ssRatio", "2", "--startSeqID", "0", "--seqNum", "2", "--batchSize", "5", "--qps", "22,37", "--hostBlocks"])
+    names = sorted(os.listdir(out / "j1" / "PartitionMat"))
+    assert names == sorted(os.listdir(out2 / "j1" / "PartitionMat")) and len(names) == 8
+    for nm in names:
+        assert open(out / "j1" / "PartitionMat" / nm, "rb").read() == open(out2 / "j1" / "PartitionMat" / nm, "rb").read(), nm
 
 
 def test_config4_4k_frame_sharded_equals_unsharded(eng, oracle_lib):
