@@ -136,6 +136,14 @@ int64_t pmp_format_partition_text(int frames, int height, int width, const uint8
 int pmp_write_partition_binary(const char *path, int frames, int height, int width, const uint8_t *hor, const uint8_t *ver,
                                const uint8_t *qt_u8, const int8_t *dire_i8);
 
+/* ---- in-process hand-over: the same frame matrices straight into caller memory, in the shapes the
+ *      patched VTM allocates in EncAppCfg::parsePartitionMatrix (EncAppCfg.cpp:4270-4298; Rom.h:240-248), one component:
+ *        hor, ver: u8[frames][rows][cols]   qt: u8[frames][rows/2][cols/2]   dire: i8[frames][3][rows][cols]
+ *      with rows = 16*(height>>6), cols = 16*(width>>6) (4x4 luma units of the picture cropped to multiples of 64).
+ *      A hook that replaces the text parser copies (or points) partitionHorMat[f][comp] etc. at these rows. ---- */
+int pmp_tile_partition_maps(int frames, int height, int width, const uint8_t *hor, const uint8_t *ver, const uint8_t *qt_u8,
+                            const int8_t *dire_i8, uint8_t *out_hor, uint8_t *out_ver, uint8_t *out_qt, int8_t *out_dire);
+
 /* ---- per-kernel-class timing with hipEvents on the launch stream (bench.py roofline leg). -------------- */
 /* mask: bit i enables kernel class i (see pmp_ktime_name); 0 disables.  Resets the accumulators. */
 int pmp_ktime_enable(pmp_ctx *ctx, uint32_t mask);

@@ -45,6 +45,7 @@ SIGNATURES = {
     "pmp_cut_blocks_device": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP]),
     "pmp_write_partition_file": (_I, [C.c_char_p, _I, _I, _I, _VP, _VP, _VP, _VP]),
     "pmp_write_partition_binary": (_I, [C.c_char_p, _I, _I, _I, _VP, _VP, _VP, _VP]),
+    "pmp_tile_partition_maps": (_I, [_I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "pmp_format_partition_text": (_I64, [_I, _I, _I, _VP, _VP, _VP, _VP, _VP, _I64]),
     "pmp_ktime_enable": (_I, [_VP, _U32]),
     "pmp_ktime_classes": (_I, []),

@@ -674,6 +674,30 @@ int pmp_write_partition_binary(const char *path, int frames, int H, int W, const
     return PMP_OK;
 }
 
+int pmp_tile_partition_maps(int frames, int H, int W, const uint8_t *hor, const uint8_t *ver, const uint8_t *qt_u8,
+                            const int8_t *dire, uint8_t *out_hor, uint8_t *out_ver, uint8_t *out_qt, int8_t *out_dire)
+{
+    if (frames < 0 || H < 0 || W < 0 || !hor || !ver || !qt_u8 || !dire || !out_hor || !out_ver || !out_qt || !out_dire)
+        return set_err(nullptr, PMP_E_INVALID, "pmp_tile_partition_maps: bad arguments");
+    const int bh = H / 64, bw = W / 64, R = 16 * bh, C = 16 * bw;
+    for (int f = 0; f < frames; ++f) {
+        const int64_t base = (int64_t)f * bh * bw;
+        for (int r = 0; r < R; ++r)
+            for (int cc = 0; cc < C; ++cc) {
+                const int64_t blk = base + (r >> 4) * bw + (cc >> 4);
+                const int cell = (r & 15) * 16 + (cc & 15);
+                const int64_t o = ((int64_t)f * R + r) * C + cc;
+                out_hor[o] = hor[blk * 256 + cell];
+                out_ver[o] = ver[blk * 256 + cell];
+                for (int k = 0; k < 3; ++k) out_dire[(((int64_t)f * 3 + k) * R + r) * C + cc] = dire[blk * 768 + k * 256 + cell];
+            }
+        for (int r = 0; r < R / 2; ++r)
+            for (int cc = 0; cc < C / 2; ++cc)
+                out_qt[((int64_t)f * (R / 2) + r) * (C / 2) + cc] = qt_u8[(base + (r >> 3) * bw + (cc >> 3)) * 64 + (r & 7) * 8 + (cc & 7)];
+    }
+    return PMP_OK;
+}
+
 // ---- timing ------------------------------------------------------------------------------------------------
 int pmp_ktime_classes(void) { return K_NCLASS; }
 

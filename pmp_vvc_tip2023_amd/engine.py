@@ -231,6 +231,22 @@ def write_partition_binary(path, frames, height, width, hor, ver, qt_u8, dire_i8
     _lib.check(lib.pmp_write_partition_binary(str(path).encode(), int(frames), int(height), int(width), _ptr(hor), _ptr(ver), _ptr(q8), _ptr(d8)))
 
 
+def tile_partition_maps(frames, height, width, hor, ver, qt_u8, dire_i8):
+    """Per-block flags -> the frame matrices the patched VTM keeps after parsing (EncAppCfg.cpp:4270-4298): hor, ver
+    u8[F][R][C], qt u8[F][R/2][C/2], dire i8[F][3][R][C], R = 16*(H>>6), C = 16*(W>>6) (pmp_tile_partition_maps)."""
+    lib = _lib.load()
+    R, Cc = 16 * (height // 64), 16 * (width // 64)
+    hor, ver, qt_u8 = _u8(hor), _u8(ver), _u8(qt_u8)
+    dire_i8 = np.ascontiguousarray(dire_i8, dtype=np.int8)
+    oh = np.zeros((frames, R, Cc), np.uint8); ov = np.zeros_like(oh)
+    oq = np.zeros((frames, R // 2, Cc // 2), np.uint8); od = np.zeros((frames, 3, R, Cc), np.int8)
+    rc = lib.pmp_tile_partition_maps(frames, height, width, _ptr(hor), _ptr(ver), _ptr(qt_u8), _ptr(dire_i8), _ptr(oh), _ptr(ov),
+                                     _ptr(oq), _ptr(od))
+    if rc != 0:
+        raise _lib.PmpError(rc, lib.pmp_last_error(None).decode())
+    return oh, ov, oq, od
+
+
 def read_partition_binary(path):
     """-> (frames, height, width, hor[F,R,C] u8, ver[F,R,C] u8, qt[F,R/2,C/2] u8, dire[F,3,R,C] i8) via numpy.memmap."""
     raw = np.memmap(path, dtype=np.uint8, mode="r")

@@ -97,6 +97,9 @@ def test_binary_side_channel_equals_text(lib, comp, tmp_path, oracle_lib):
     th, tv, tq, td = engine.read_partition_file(golden_path("g5_partitionmat_%s.txt" % comp), F, H, W)
     assert np.array_equal(bh, th) and np.array_equal(bv, tv) and np.array_equal(bq, tq) and np.array_equal(bd, td)
     assert os.path.getsize(pb) == 40 + F * (5 * 16 * 32 + 8 * 16)
+    # N4 (library side): the same frame matrices straight into caller memory, the shapes parsePartitionMatrix allocates
+    mh, mv, mq, md = engine.tile_partition_maps(F, H, W, hor, ver, q.astype(np.uint8), dout)
+    assert np.array_equal(mh, th) and np.array_equal(mv, tv) and np.array_equal(mq, tq) and np.array_equal(md, td)
 
 
 @pytest.mark.parametrize("cout,cin,k", [(64, 64, 3), (32, 17, 5), (8, 32, 1), (64, 32, 5)])
