@@ -105,7 +105,11 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
     // latency here is longer than one 3x3 group).  Plain mode keeps one set and a distance of one group.
     // 5x5 groups (12.5 K-steps) outlast the HBM latency on their own; the Cout <= 32 kernels are latency-bound small layers
     // that gain more from a third resident workgroup (168 VGPRs) than from the second staging set
-    constexpr bool DEEP = G::TAPS <= 9 && NT == 4;
+    // W0DB: the next K-step's w0 fragments are requested at the TOP of a K-step into a second register set and moved over at
+    // its end (8 v_mov) - a full K-step of lead for the split that is used last and needed first; taken from the second
+    // halo staging set's registers.
+    constexpr bool W0DB = NT == 4;
+    constexpr bool DEEP = G::TAPS <= 9 && NT == 4 && !W0DB;
     u32x4 r[G::NLD], rb[DEEP ? G::NLD : 1];
     StagePlanH<KH, KW> plan;
     h2_plan<KH, KW>(plan, plane_stride, H, W, ty, tx);
@@ -186,6 +190,11 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
                 else h2_stage_load<KH, KW>(plan, nxt_grp, rl, ks * PER, (ks + 1) * PER);
             }
             const f16x8 *wf = wl + (size_t)min(stream, last) * (2 * NT * 64);   // next K-step's fragments (L2-resident)
+            f16x8 w0n[CW];
+            if (W0DB && !(ABL & 2)) {
+#pragma unroll
+                for (int nt = 0; nt < CW; ++nt) w0n[nt] = wf[(0 * NT + nt) * 64];
+            }
             __builtin_amdgcn_sched_barrier(0);
             // phase A: x0*w1, then w1 is free for the next K-step's fragments
 #pragma unroll
@@ -218,7 +227,7 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
             __builtin_amdgcn_sched_barrier(0);
             if (!(ABL & 2)) {
 #pragma unroll
-                for (int nt = 0; nt < CW; ++nt) w0[nt] = wf[(0 * NT + nt) * 64];
+                for (int nt = 0; nt < CW; ++nt) w0[nt] = W0DB ? w0n[nt] : wf[(0 * NT + nt) * 64];
             }
             __builtin_amdgcn_sched_barrier(0);
         }
