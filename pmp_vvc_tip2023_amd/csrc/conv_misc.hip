@@ -129,9 +129,135 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
     }
 }
 
+// ---- MFMA stem (f16x3 datapath).  The same first layers as stem_kernel, as ONE top-left anchored K1 x K1 convolution with 32
+// outputs on the fp16 matrix cores: pixels (0..255) are exact in fp16, so they need one term; the plane built from the QT
+// logits gets the usual two (x0, x1); weights are two scaled fp16 terms (pack_stem_h2).  Products: x0*w0 + x0*w1 (+ x1*w0
+// for the logit plane).  There is no channel dimension to make a lane's 8 K-values contiguous - they are 8 consecutive
+// pixels of an input row starting at an arbitrary column - so the B fragments are gathered with 2-byte LDS reads; one
+// gathered fragment feeds 4-6 MFMAs (two cout groups x the products).  Workgroup = one block; a wave walks batches of 8
+// rows x 16 columns (64 accumulator VGPRs) and streams the weight fragments from L2 once per batch and K-step.
+template <bool LUMA, bool MSBD>
+__global__ __launch_bounds__(256) void stem_mfma_kernel(StemArgs a)
+{
+    constexpr int S = LUMA ? 68 : 34, P = LUMA ? 4 : 2, PS = S + P, OUT = S - P;   // 72/36 planes, 64/32 outputs
+    constexpr int CIN = (LUMA ? 1 : 3) + (MSBD ? 1 : 0);
+    constexpr int K1 = LUMA ? 9 : 5;
+    constexpr int DXW = K1 > 8 ? 16 : 8, RPK = 32 / DXW;
+    constexpr int CINP = (RPK % CIN == 0) ? CIN : 4;          // chroma QT: 3 planes padded to 4 (zero weights)
+    constexpr int NROW = K1 * CINP, KS = (NROW + RPK - 1) / RPK, STEP = RPK / CINP;
+    static_assert(RPK % CINP == 0 && STEP >= 1, "every lane's input row must advance by the same step per K-step");
+    constexpr int RS = PS + 16;                          // row stride: a fragment may run 15 columns past the last pixel (zero weights there)
+    constexpr int SEGS = OUT / 16, RB = 8, NBATCH = SEGS * (OUT / RB);
+    __shared__ _Float16 h0[CIN * PS * RS + 16];
+    __shared__ _Float16 h1[MSBD ? PS * RS + 16 : 8];     // low term of the logit plane
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, xl = lane & 15, g = lane >> 4;
+
+    const uint8_t *by = a.by + (size_t)n * 68 * 68;
+    for (int i = tid; i < PS * RS; i += 256) {
+        const int r = i / RS, c = i - r * RS;
+        const bool in = r < S && c < S;
+        if (LUMA) {
+            h0[i] = in ? (_Float16)(float)by[r * 68 + c] : (_Float16)0.f;
+        } else {
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+            if (in) {
+                const uint8_t *p = by + (2 * r) * 68 + 2 * c;  // F.max_pool2d(Y, 2), Inference_QBD.py:197
+                v0 = (float)max(max((int)p[0], (int)p[1]), max((int)p[68], (int)p[69]));
+                v1 = (float)a.bu[(size_t)n * 34 * 34 + r * 34 + c];
+                v2 = (float)a.bv[(size_t)n * 34 * 34 + r * 34 + c];
+            }
+            h0[i] = (_Float16)v0; h0[PS * RS + i] = (_Float16)v1; h0[2 * PS * RS + i] = (_Float16)v2;
+        }
+        if (MSBD) {  // padding_lu(interpolate(q, 8 | 4)), Model_QBD.py:130 / :228
+            float qv = 0.f;
+            if (in && r >= P && c >= P) {
+                constexpr int SC = LUMA ? 8 : 4;
+                qv = a.q[(size_t)n * 64 + ((r - P) / SC) * 8 + (c - P) / SC];
+            }
+            _Float16 q0, q1;
+            split2(qv, q0, q1);
+            h0[(CIN - 1) * PS * RS + i] = q0; h1[i] = q1;
+        }
+    }
+    __syncthreads();
+
+    // K rows are (dy, ci) with ci padded to CINP so that every lane's input row advances by the same STEP per K-step:
+    // lane group g reads row  y + ks*STEP + dyoff  of plane ci.  The 8 fragments of a batch (output rows m = 0..7) then form a
+    // sliding window over input rows: a K-step gathers only STEP new fragments (16 or 8 two-byte reads) instead of 8.
+    const f16x8 *wl = reinterpret_cast<const f16x8 *>(a.wh) + lane;
+    const float inv_scale = a.out_scale;
+    const size_t out_n = (size_t)n * 2 * OUT * OUT * 16;
+    const int kr0 = DXW == 16 ? (g >> 1) : g;                 // this lane's K row inside a K-step
+    const int dx0 = DXW == 16 ? 8 * (g & 1) : 0;
+    const int dyoff = kr0 / CINP, ci = min(kr0 - dyoff * CINP, CIN - 1);   // padded channel: zero weights, any valid plane
+    const bool qrow = MSBD && (kr0 - dyoff * CINP) == CIN - 1;
+    auto gather = [&](const _Float16 *p) {
+        f16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = p[j];
+        return v;
+    };
+    for (int b = wave; b < NBATCH; b += 4) {
+        const int seg = b % SEGS, y0 = (b / SEGS) * RB, x0 = seg * 16;
+        // row index clamped: the window runs up to STEP-1 rows past the last row a real tap needs (zero weights there)
+        const _Float16 *base = h0 + (ci * PS) * RS + x0 + xl + dx0;
+        const _Float16 *base1 = h1 + x0 + xl + dx0;
+        auto row = [&](int p) { return min(y0 + dyoff + p, PS - 1) * RS; };
+        f32x4 acc[RB][2];
+        f16x8 win[RB], win1[MSBD ? RB : 1];
+#pragma unroll
+        for (int m = 0; m < RB; ++m) {
+            acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            win[m] = gather(base + row(m));
+            if (MSBD) win1[m] = qrow ? gather(base1 + row(m)) : (f16x8)(_Float16)0.f;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f16x8 *wk = wl + (size_t)ks * (2 * 2 * 64);
+            const f16x8 w00 = wk[0], w01 = wk[64], w10 = wk[128], w11 = wk[192];   // [split][nt]
+#pragma unroll
+            for (int m = 0; m < RB; ++m) {
+                const f16x8 bx = win[(m + ks * STEP) & 7];
+                acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w00, bx, acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01, bx, acc[m][1], 0, 0, 0);
+                acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w10, bx, acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w11, bx, acc[m][1], 0, 0, 0);
+                if (MSBD) {
+                    const f16x8 b1 = win1[(m + ks * STEP) & 7];
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w00, b1, acc[m][0], 0, 0, 0);
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01, b1, acc[m][1], 0, 0, 0);
+                }
+            }
+            if (ks + 1 < KS) {   // slide the window: positions 8 + ks*STEP .. replace the oldest STEP slots
+#pragma unroll
+                for (int t = 0; t < STEP; ++t) {
+                    const int p = RB + ks * STEP + t;
+                    win[p & 7] = gather(base + row(p));
+                    if (MSBD) win1[p & 7] = qrow ? gather(base1 + row(p)) : (f16x8)(_Float16)0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const f32x4 bias = *reinterpret_cast<const f32x4 *>(a.bias + nt * 16 + g * 4);
+#pragma unroll
+            for (int m = 0; m < RB; ++m) {
+                f32x4 v = acc[m][nt] * inv_scale + bias;
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                const size_t o = out_n + (((size_t)nt * OUT + (y0 + m)) * OUT + x0 + xl) * 16 + g * 4;
+                store_split2_4(a.out_s3 + o, a.s3_stride, v);
+            }
+        }
+    }
+}
+
 template <bool LUMA, bool MSBD>
 static hipError_t launch_stem_t(hipStream_t s, const StemArgs &a)
 {
+    if (a.out_s3 && a.fmt == FMT_H2 && a.wh) {
+        hipLaunchKernelGGL((stem_mfma_kernel<LUMA, MSBD>), dim3(a.N), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     constexpr int S = LUMA ? 68 : 34, P = LUMA ? 4 : 2, PS = S + P;
     constexpr int CIN = (LUMA ? 1 : 3) + (MSBD ? 1 : 0);
     constexpr int K1 = LUMA ? 9 : 5, K2 = LUMA ? 5 : 3;

@@ -143,7 +143,8 @@ struct Graph {
         const int S = luma ? 64 : 32;
         Act o = alloc(32, S, S, x6());     // bf16x6 mode: the stem writes split-3 planes directly
         if (!live()) return o;
-        StemArgs a{by, bu, bv, q, w.stem_w, w.stem_b, o.split ? nullptr : o.p, n, o.split ? o.s() : nullptr, o.stride, fmt()};
+        StemArgs a{by, bu, bv, q, w.stem_w, w.stem_b, o.split ? nullptr : o.p, n, o.split ? o.s() : nullptr, o.stride, fmt(),
+                   h2() ? w.stem_wh : nullptr, std::ldexp(1.f, -w.stem_k)};
         const int cin = (luma ? 1 : 3) + (msbd ? 1 : 0), k1 = luma ? 9 : 5, k2 = luma ? 5 : 3;
         const double macs = msbd ? (double)cin * (k1 * k1 * 16 + 2 * k1 * k2 * 8) : (double)cin * k1 * k1 * 32;
         KScope ks(c, K_STEM, 2.0 * n * S * S * macs);

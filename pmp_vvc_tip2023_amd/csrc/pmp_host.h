@@ -34,6 +34,7 @@ struct NetWeights {
     bool loaded = false;
     std::map<std::string, RBWeights> rb;
     float *stem_w = nullptr, *stem_b = nullptr;        // packed stem convs + 32 biases
+    unsigned short *stem_wh = nullptr; int stem_k = 0; // f16x3 MFMA stem: fragment stream, scaled by 2^stem_k
     float *head_w[3] = {nullptr, nullptr, nullptr};    // [9][8][cout]
     float *head_b[3] = {nullptr, nullptr, nullptr};
     std::vector<void *> allocs;
@@ -86,6 +87,7 @@ std::vector<float> pack_mfma(const float *w, int cout, int cin, int kh, int kw, 
 std::vector<unsigned short> pack_x6(const float *w, int cout, int cin, int kh, int kw, int cout_pad, int cin_pad);
 std::vector<unsigned short> pack_h2(const float *w, int cout, int cin, int kh, int kw, int cout_pad, int cin_pad, int scale_exp);
 int h2_scale_exp(const float *w, size_t n);
+std::vector<unsigned short> pack_stem_h2(const float *w32, int cin, int k1, int scale_exp);
 
 // nets.cpp: forward graphs on device pointers (n <= chunk); all launches go to c->stream.
 int forward_q(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, const uint8_t *bu, const uint8_t *bv,

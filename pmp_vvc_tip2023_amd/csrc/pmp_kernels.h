@@ -67,6 +67,7 @@ struct StemArgs {
     int N;
     unsigned short *out_s3; size_t s3_stride;   // if out_s3 != nullptr the 32 channels are written as split planes ...
     int fmt;                                    // ... of format 1 (three bf16) or 2 (two fp16), see split3.h
+    const unsigned short *wh; float out_scale;  // fmt 2: fp16 fragment stream (pack_stem_h2) and 1/scale -> the MFMA stem
 };
 hipError_t launch_stem(hipStream_t s, bool luma, bool msbd, const StemArgs &a);
 

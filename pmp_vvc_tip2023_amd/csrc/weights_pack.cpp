@@ -184,6 +184,39 @@ std::vector<unsigned short> pack_h2(const float *w, int cout, int cin, int kh, i
     return out;
 }
 
+// Stem weights for the MFMA stem (conv_misc.hip: stem_mfma_kernel): ONE k1 x k1 convolution with 32 outputs, top-left
+// anchored (the smaller kernels of the MTT stems are zero-padded into it).  w32: [32][cin][k1][k1].  K is ordered
+// (dy, ci, dx) with dx padded to DXW = 16 (k1 > 8) or 8 slots and ci padded so that it divides 32/DXW; a K-step of 32 covers
+// 32/DXW (dy, ci) rows.
+// Stream: [K-step][2 splits][2 cout groups][64 lanes][8] fp16 terms of 2^scale_exp * w.
+std::vector<unsigned short> pack_stem_h2(const float *w32, int cin, int k1, int scale_exp)
+{
+    const int DXW = k1 > 8 ? 16 : 8, RPK = 32 / DXW;
+    const int cinp = (RPK % cin == 0) ? cin : 4;   // chroma QT: 3 planes padded to 4 so a lane's input row advances uniformly
+    const int NROW = k1 * cinp, KS = (NROW + RPK - 1) / RPK;
+    const float S = std::ldexp(1.f, scale_exp);
+    auto bits = [](_Float16 h) { unsigned short u; std::memcpy(&u, &h, 2); return u; };
+    std::vector<unsigned short> out((size_t)KS * 2 * 2 * 64 * 8, 0);
+    for (int ks = 0; ks < KS; ++ks)
+        for (int nt = 0; nt < 2; ++nt)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int g = l >> 4, co = nt * 16 + (l & 15);
+                    const int kr = DXW == 16 ? RPK * ks + (g >> 1) : RPK * ks + g;
+                    const int dx = (DXW == 16 ? 8 * (g & 1) : 0) + j;
+                    float v = 0.f;
+                    if (kr < NROW && dx < k1) {
+                        const int dy = kr / cinp, ci = kr % cinp;
+                        if (ci < cin) v = w32[(((size_t)co * cin + ci) * k1 + dy) * k1 + dx] * S;
+                    }
+                    const _Float16 h0 = (_Float16)v;
+                    const _Float16 h1 = (_Float16)(v - (float)h0);
+                    out[((((size_t)ks * 2 + 0) * 2 + nt) * 64 + l) * 8 + j] = bits(h0);
+                    out[((((size_t)ks * 2 + 1) * 2 + nt) * 64 + l) * 8 + j] = bits(h1);
+                }
+    return out;
+}
+
 namespace {
 
 // OIHW -> [tap][cin][cout] (direct kernels, stems, heads)
@@ -279,6 +312,8 @@ int load_net_weights(pmp_ctx *c, int net_id, int qp, const float *blob, const pm
         if ((rc = need(c, b, "conv_q1.bias", {32}, &bias))) return fail(rc);
         if ((rc = up.upload(pack_plain(w, 32, cin, k1, k1), &nw.stem_w))) return fail(rc);
         if ((rc = up.upload(std::vector<float>(bias, bias + 32), &nw.stem_b))) return fail(rc);
+        nw.stem_k = h2_scale_exp(w, (size_t)32 * cin * k1 * k1);
+        if ((rc = up.upload16(pack_stem_h2(w, cin, k1, nw.stem_k), &nw.stem_wh))) return fail(rc);
         if ((rc = load_rb(c, b, up, "resblock_q1", 32, 64, kq, false))) return fail(rc);
         if ((rc = load_rb(c, b, up, "resblock_q2", 64, 64, kq, false))) return fail(rc);
         if ((rc = load_rb(c, b, up, "resblock_q3", 64, 32, 3, false))) return fail(rc);
@@ -305,6 +340,22 @@ int load_net_weights(pmp_ctx *c, int net_id, int qp, const float *blob, const pm
         sb.insert(sb.end(), b3, b3 + 8);
         if ((rc = up.upload(sw, &nw.stem_w))) return fail(rc);
         if ((rc = up.upload(sb, &nw.stem_b))) return fail(rc);
+        {   // the three stem convs as one top-left anchored k1 x k1 conv (the 5x9 / 9x5 kernels zero-padded), for the MFMA stem
+            std::vector<float> w32((size_t)32 * cin * k1 * k1, 0.f);
+            for (int co = 0; co < 16; ++co)
+                for (int i = 0; i < cin * k1 * k1; ++i) w32[(size_t)co * cin * k1 * k1 + i] = w1[(size_t)co * cin * k1 * k1 + i];
+            for (int co = 0; co < 8; ++co)
+                for (int ci = 0; ci < cin; ++ci) {
+                    for (int dy = 0; dy < k2; ++dy)
+                        for (int dx = 0; dx < k1; ++dx)
+                            w32[((((size_t)(16 + co)) * cin + ci) * k1 + dy) * k1 + dx] = w2[(((size_t)co * cin + ci) * k2 + dy) * k1 + dx];
+                    for (int dy = 0; dy < k1; ++dy)
+                        for (int dx = 0; dx < k2; ++dx)
+                            w32[((((size_t)(24 + co)) * cin + ci) * k1 + dy) * k1 + dx] = w3[(((size_t)co * cin + ci) * k1 + dy) * k2 + dx];
+                }
+            nw.stem_k = h2_scale_exp(w32.data(), w32.size());
+            if ((rc = up.upload16(pack_stem_h2(w32.data(), cin, k1, nw.stem_k), &nw.stem_wh))) return fail(rc);
+        }
         if ((rc = load_rb(c, b, up, "trunk_M1.0", 32, 64, 5, false))) return fail(rc);
         for (int i = 1; i < 6; ++i)
             if ((rc = load_rb(c, b, up, "trunk_M1." + std::to_string(i), 64, 64, 3, false))) return fail(rc);
