@@ -62,7 +62,9 @@ __device__ __forceinline__ void region_sums(Search &s, const int (&btm)[4], cons
 {
     const int lane = threadIdx.x & 63;
     const int n = s.rh * s.rw;
-    __syncthreads();
+    // wave-local ordering only (the scratch is private to the wave and the four waves of a block search different quadrants,
+    // so a workgroup barrier here would not even be reached the same number of times)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int r = s.row - s.rx, c = s.col0 + k - s.ry;
@@ -72,7 +74,7 @@ __device__ __forceinline__ void region_sums(Search &s, const int (&btm)[4], cons
             s.vald[f] = fabsf((float)drm[k] - od[k]);
         }
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const float *v = (lane & 16) ? s.vald : s.valb;
     const int j = lane & 15, half = j >> 3, k = j & 7;
     float r = 0.f;
@@ -244,17 +246,21 @@ __device__ __forceinline__ void expand(Search &s)
 }  // namespace
 
 // One wave per block.  LDS per workgroup: 2 x 256 floats (sum scratch) + 2 x 256 bytes (edge planes).
-__global__ __launch_bounds__(64) void postprocess_kernel(const float *__restrict__ qt, const float *__restrict__ bt,
-                                                         const float *__restrict__ dire, int64_t N, int cf,
-                                                         uint8_t *__restrict__ hor_o, uint8_t *__restrict__ ver_o,
-                                                         uint8_t *__restrict__ qt_o, int8_t *__restrict__ dire_o)
+// Four waves per block: the QT leaves under the four 32x32 quadrants are independent searches writing disjoint cells, so wave
+// w takes the nodes of quadrant w (a block that is one 64x64 leaf is searched by wave 0 alone).  Every wave keeps the whole
+// block's maps - the search code is the single-wave one - and has its own pairwise-sum scratch.
+__global__ __launch_bounds__(256) void postprocess_kernel(const float *__restrict__ qt, const float *__restrict__ bt,
+                                                          const float *__restrict__ dire, int64_t N, int cf,
+                                                          uint8_t *__restrict__ hor_o, uint8_t *__restrict__ ver_o,
+                                                          uint8_t *__restrict__ qt_o, int8_t *__restrict__ dire_o)
 {
-    __shared__ float valb[256], vald[256];
+    __shared__ float valb_all[4][256], vald_all[4][256];
     __shared__ uint32_t horw[64], verw[64];
     uint8_t *hor = reinterpret_cast<uint8_t *>(horw), *ver = reinterpret_cast<uint8_t *>(verw);
     const int64_t b = blockIdx.x;
     if (b >= N) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float *valb = valb_all[wv], *vald = vald_all[wv];
 
     // ---- eli_structual_error (Metrics.py:630-637): lanes 0..15 own the 4x4 pooled map
     float pv = 0.f;
@@ -286,7 +292,7 @@ __global__ __launch_bounds__(64) void postprocess_kernel(const float *__restrict
     }
     // nearest x2 (Metrics.py:635): lane l holds the 8x8 value at (l>>3, l&7)
     const int qt8 = rlane(m, 0) * 0 + __shfl(m, ((lane >> 4) << 2) + ((lane & 7) >> 1));
-    qt_o[b * 64 + lane] = (uint8_t)qt8;
+    if (wv == 0) qt_o[b * 64 + lane] = (uint8_t)qt8;
 
     // ---- Map_to_Partition.__init__ (Map2Partition.py:100-122)
     Search s;
@@ -310,8 +316,7 @@ __global__ __launch_bounds__(64) void postprocess_kernel(const float *__restrict
             s.md[k3][k] = fd[k] >= 0.5f ? 1 : (fd[k] <= -0.5f ? -1 : 0);
         }
     }
-    horw[lane] = 0;
-    verw[lane] = 0;
+    if (wv == 0) { horw[lane] = 0; verw[lane] = 0; }
     int outd[3][4];
 #pragma unroll
     for (int k3 = 0; k3 < 3; ++k3)
@@ -330,6 +335,7 @@ __global__ __launch_bounds__(64) void postprocess_kernel(const float *__restrict
                 if (!(rlane(qt8, (qx & am) * 8 + (qy & am)) > a)) reached = false;
             }
             if (!reached) continue;
+            if (wv != (d == 0 ? 0 : ((qx >= 4 ? 2 : 0) + (qy >= 4 ? 1 : 0)))) continue;   // another wave's quadrant
             const int c = rlane(qt8, qx * 8 + qy);
             if (c > d) {
                 if (d < 3 && lane < 2 * sms) {            // paint the QT cross
@@ -370,13 +376,20 @@ __global__ __launch_bounds__(64) void postprocess_kernel(const float *__restrict
         }
     }
     __syncthreads();
-    reinterpret_cast<uint32_t *>(hor_o + b * 256)[lane] = horw[lane];
-    reinterpret_cast<uint32_t *>(ver_o + b * 256)[lane] = verw[lane];
+    if (wv == 0) {
+        reinterpret_cast<uint32_t *>(hor_o + b * 256)[lane] = horw[lane];
+        reinterpret_cast<uint32_t *>(ver_o + b * 256)[lane] = verw[lane];
+    }
+    // a lane's four cells (row lane>>2, columns 4*(lane&3)..+3) lie in one quadrant: its owner holds their directions
+    const bool whole = rlane(qt8, 0) == 0;   // the block is one 64x64 leaf: wave 0 searched it
+    const int quad = ((lane >> 2) >= 8 ? 2 : 0) + ((lane & 3) >= 2 ? 1 : 0);
+    if (whole ? wv == 0 : wv == quad) {
 #pragma unroll
-    for (int k3 = 0; k3 < 3; ++k3) {
-        const uint32_t wv = (uint32_t)(uint8_t)outd[k3][0] | ((uint32_t)(uint8_t)outd[k3][1] << 8) |
-                            ((uint32_t)(uint8_t)outd[k3][2] << 16) | ((uint32_t)(uint8_t)outd[k3][3] << 24);
-        reinterpret_cast<uint32_t *>(dire_o + (b * 3 + k3) * 256)[lane] = wv;
+        for (int k3 = 0; k3 < 3; ++k3) {
+            const uint32_t pk = (uint32_t)(uint8_t)outd[k3][0] | ((uint32_t)(uint8_t)outd[k3][1] << 8) |
+                                ((uint32_t)(uint8_t)outd[k3][2] << 16) | ((uint32_t)(uint8_t)outd[k3][3] << 24);
+            reinterpret_cast<uint32_t *>(dire_o + (b * 3 + k3) * 256)[lane] = pk;
+        }
     }
 }
 
@@ -384,7 +397,7 @@ hipError_t launch_postprocess(hipStream_t st, const float *qt, const float *bt, 
                               int chroma_factor, uint8_t *hor, uint8_t *ver, uint8_t *qt_u8, int8_t *dire_i8)
 {
     if (N <= 0) return hipSuccess;
-    hipLaunchKernelGGL(postprocess_kernel, dim3((unsigned)N), dim3(64), 0, st, qt, bt, dire, N, chroma_factor, hor, ver,
+    hipLaunchKernelGGL(postprocess_kernel, dim3((unsigned)N), dim3(256), 0, st, qt, bt, dire, N, chroma_factor, hor, ver,
                        qt_u8, dire_i8);
     return hipGetLastError();
 }
