@@ -314,8 +314,85 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvDirectArgs a)
     a.out[act_idx(n, co, y, x, CBo, a.H, a.W)] = acc;  // padded channels are written as zeros
 }
 
+// Fast path of the same operation for Cout <= 8 (the 8x8 tail of the QT nets): one thread per pixel computes all couts,
+// weights sit in LDS as [tap][cin][8], activations come as 16-channel float4 quads.  Same accumulation order as the
+// generic kernel (bias, taps row-major, channels ascending, shortcut, residual), so the result is bit-identical.
+__global__ __launch_bounds__(256) void conv_direct8_kernel(ConvDirectArgs a)
+{
+    extern __shared__ float wl[];   // [KH*KW*Cin][8], then [Csc][8]
+    const int taps = a.KH * a.KW, nw = taps * a.Cin;
+    for (int i = threadIdx.x; i < (nw + (a.x_sc ? a.Csc : 0)) * 8; i += 256) {
+        const int row = i >> 3, co = i & 7;
+        float v = 0.f;
+        if (co < a.Cout) v = row < nw ? a.w[(size_t)row * a.Cout + co] : a.w_sc[(size_t)(row - nw) * a.Cout + co];
+        wl[i] = v;
+    }
+    __syncthreads();
+    const size_t total = (size_t)a.N * a.H * a.W;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % a.W), y = (int)((i / a.W) % a.H), n = (int)(i / ((size_t)a.W * a.H));
+    const int CBi = a.CinPad >> 4, CBo = a.CoutPad >> 4, py = a.KH / 2, px = a.KW / 2;
+    float acc[8];
+#pragma unroll
+    for (int co = 0; co < 8; ++co) acc[co] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+    auto mac16 = [&](const float *xp, const float *wp, int nch) {   // up to 16 consecutive channels of one pixel
+        const f32x4 q0 = *reinterpret_cast<const f32x4 *>(xp), q1 = *reinterpret_cast<const f32x4 *>(xp + 4),
+                    q2 = *reinterpret_cast<const f32x4 *>(xp + 8), q3 = *reinterpret_cast<const f32x4 *>(xp + 12);
+        const float v[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            if (c < nch) {
+                const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wp + c * 8), w1 = *reinterpret_cast<const f32x4 *>(wp + c * 8 + 4);
+                acc[0] = fmaf(v[c], w0.x, acc[0]); acc[1] = fmaf(v[c], w0.y, acc[1]); acc[2] = fmaf(v[c], w0.z, acc[2]); acc[3] = fmaf(v[c], w0.w, acc[3]);
+                acc[4] = fmaf(v[c], w1.x, acc[4]); acc[5] = fmaf(v[c], w1.y, acc[5]); acc[6] = fmaf(v[c], w1.z, acc[6]); acc[7] = fmaf(v[c], w1.w, acc[7]);
+            }
+        }
+    };
+    for (int dy = 0; dy < a.KH; ++dy) {
+        const int yy = y + dy - py;
+        if (yy < 0 || yy >= a.H) continue;
+        for (int dx = 0; dx < a.KW; ++dx) {
+            const int xx = x + dx - px;
+            if (xx < 0 || xx >= a.W) continue;
+            for (int c0 = 0; c0 < a.Cin; c0 += 16)
+                mac16(a.x + act_idx(n, c0, yy, xx, CBi, a.H, a.W), wl + ((dy * a.KW + dx) * a.Cin + c0) * 8, min(16, a.Cin - c0));
+        }
+    }
+    if (a.x_sc) {
+        const int CBs = a.CscPad >> 4;
+        for (int c0 = 0; c0 < a.Csc; c0 += 16)
+            mac16(a.x_sc + act_idx(n, c0, y, x, CBs, a.H, a.W), wl + (nw + c0) * 8, min(16, a.Csc - c0));
+    }
+    float o[16];
+#pragma unroll
+    for (int co = 0; co < 16; ++co) o[co] = 0.f;
+#pragma unroll
+    for (int co = 0; co < 8; ++co) {
+        float v = acc[co];
+        if (co < a.Cout) {
+            if (a.res) v += a.res[act_idx(n, co, y, x, CBo, a.H, a.W)];
+            if (a.relu) v = fmaxf(v, 0.f);
+            o[co] = v;
+        }
+    }
+    float *op = a.out + act_idx(n, 0, y, x, CBo, a.H, a.W);
+    *reinterpret_cast<f32x4 *>(op) = (f32x4){o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<f32x4 *>(op + 4) = (f32x4){o[4], o[5], o[6], o[7]};
+    *reinterpret_cast<f32x4 *>(op + 8) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4 *>(op + 12) = (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+
 hipError_t launch_conv_direct(hipStream_t s, const ConvDirectArgs &a)
 {
+    if (a.Cout <= 8 && a.CoutPad == 16 && (a.CinPad & 15) == 0 && (!a.x_sc || (a.CscPad & 15) == 0)) {
+        const size_t px = (size_t)a.N * a.H * a.W;
+        const size_t smem = (size_t)(a.KH * a.KW * a.Cin + (a.x_sc ? a.Csc : 0)) * 8 * sizeof(float);
+        if (smem <= 48 * 1024) {
+            hipLaunchKernelGGL(conv_direct8_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), smem, s, a);
+            return hipGetLastError();
+        }
+    }
     const size_t total = (size_t)a.N * a.H * a.W * a.CoutPad;
     hipLaunchKernelGGL(conv_direct_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
