@@ -275,7 +275,7 @@ def test_driver_end_to_end_files(eng, oracle_lib, tmp_path):
         with open(cfg / (name + ".cfg"), "w") as f:
             f.write("InputFile                     : %s   # comment\nInputBitDepth                 : %d\n" % (fn, bd))
     D.main(["--jobID", "j1", "--inputDir", str(inp), "--outDir", str(out), "--seqTable", "table.txt", "--cfgDir", str(cfg),
-            "--ssRatio", "2", "--startSeqID", "0", "--seqNum", "2", "--batchSize", "5", "--qps", "22,37"])
+            "--ssRatio", "2", "--startSeqID", "0", "--seqNum", "2", "--batchSize", "5", "--strictBatch", "--qps", "22,37"])
     for name, fn, w, h, fr, bd in seqs:
         y, u, v = planes[name]
         by, bu, bv = oracle_lib.cut_blocks(y[::2], u[::2], v[::2], bd)
