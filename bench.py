@@ -43,8 +43,10 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(sample_blocks, seed):
-    """The oracle (a port of the reference's torch CPU path + C post-processing) on this host's cores."""
+def cpu_baseline(sample_blocks, seed, eng=None):
+    """The oracle (a port of the reference's torch CPU path + C post-processing) on this host's cores.  With `eng`, the same
+    sample also goes through the HIP path and the JSON gets a `parity` object (logits max-abs error, split-flag
+    mismatches) - the oracle is the checker here, never the thing timed as the product."""
     from oracle import nets_torch as O, postproc as P
     from pmp_vvc_tip2023_amd import synth, weights as W
     ncpu = os.cpu_count() or 1
@@ -72,13 +74,29 @@ def cpu_baseline(sample_blocks, seed):
     t0 = time.perf_counter()
     qt, bt, dire = O.infer_qbd(wq, wbd, x, True, batch=64)
     t1 = time.perf_counter()
-    P.seq_post_process(qt, bt, dire, "Luma", 1, 64 * sample_blocks, 64, None)
+    ohor, over, oq8, od8 = P.seq_post_process(qt, bt, dire, "Luma", 1, 64 * sample_blocks, 64, None)
     t2 = time.perf_counter()
     log("cpu_baseline: nets %.2fs, post-proc %.3fs for %d blocks on %d threads" % (t1 - t0, t2 - t1, sample_blocks, cores))
-    return {"value": round(sample_blocks / 4.0 / (t2 - t0), 3), "unit": "CTU/s", "cores": cores, "kind": "port",
-            "blocks_per_s": round(sample_blocks / (t2 - t0), 2),
-            "sample": "%d luma blocks QP22 (recipe R seed %d): torch-CPU fp32 QT+MTT forward (batch 64, %d threads) + "
-                      "C oracle post-processing (1 thread)" % (sample_blocks, seed, cores)}
+    out = {"value": round(sample_blocks / 4.0 / (t2 - t0), 3), "unit": "CTU/s", "cores": cores, "kind": "port",
+           "blocks_per_s": round(sample_blocks / (t2 - t0), 2),
+           "sample": "%d luma blocks QP22 (recipe R seed %d): torch-CPU fp32 QT+MTT forward (batch 64, %d threads) + "
+                     "C oracle post-processing (1 thread)" % (sample_blocks, seed, cores)}
+    parity = None
+    if eng is not None:
+        yb = np.ascontiguousarray(y[:sample_blocks])
+        gq, gb, gd = eng.inference_pre_QBD("Luma", 22, yb)
+        ghor, gver, gq8, gd8 = eng.infer_postprocess("Luma", 22, yb)
+        # flags of the device logits through the oracle's post-processing: the bit-exactness claim of the integer stage
+        phor, pver, pq8, pd8 = P.seq_post_process(gq, gb, gd, "Luma", 1, 64 * sample_blocks, 64, None)
+        parity = {"blocks": int(sample_blocks),
+                  "logit_max_abs_err": float(max(np.abs(gq - qt).max(), np.abs(gb - bt).max(), np.abs(gd - dire).max())),
+                  "tolerance": 1e-3,
+                  "flag_mismatch_vs_oracle_postproc_of_device_logits": int((ghor != phor).sum() + (gver != pver).sum() +
+                                                                          (gq8 != pq8.astype(gq8.dtype)).sum() + (gd8 != pd8).sum()),
+                  "flag_mismatch_vs_cpu_end_to_end": int((ghor != ohor).sum() + (gver != over).sum() +
+                                                         (gq8 != oq8.astype(gq8.dtype)).sum() + (gd8 != od8).sum()),
+                  "flags_compared": int(ghor.size + gver.size + gq8.size + gd8.size)}
+    return out, parity
 
 
 def main():
@@ -231,7 +249,7 @@ def main():
             "roofline": roof,
         }
         if args.cpu_sample > 0 and n_gpus == 1 and args.comp == "Luma":
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 1)
+            out["cpu_baseline"], out["parity"] = cpu_baseline(args.cpu_sample, 1, eng)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
