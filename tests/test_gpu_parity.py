@@ -374,3 +374,28 @@ def test_driver_two_ranks_equal_one_rank(tmp_path):
     assert len(names) == 4 and names == sorted(os.listdir(d2))
     for nme in names:
         assert open(d1 / nme, "rb").read() == open(d2 / nme, "rb").read(), nme
+
+
+# ------------------------------------------------------------------------------------------------ bench.py contract
+def test_bench_json_contract(tmp_path):
+    """bench.py prints ONE JSON line with the driver's fields, the roofline of the dominant kernel class measured with HIP
+    events on the launch stream, the CPU baseline of a bounded sample and the parity of that sample."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "64",
+                        "--cpu-sample", "8"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "CTU/s" and d["vs_baseline"] is None
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["data"] == "synthetic" and "workload" in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert d["parity"]["logit_max_abs_err"] < 1e-3 and d["parity"]["flag_mismatch_vs_oracle_postproc_of_device_logits"] == 0
+    assert d["value"] > 50 * cb["value"]   # sanity: the GPU path is not the CPU path
