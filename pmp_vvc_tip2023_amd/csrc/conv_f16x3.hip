@@ -14,11 +14,14 @@
 //
 // Activation format "split-2": two fp16 planes, each blocked channels-last [n][C/16][H][W][16] (32 B per pixel and
 // group), plane stride = N*C*H*W elements.  Tiling, LDS image, tap pairing and the weight stream order are those of
-// conv_bf16x6.hip (one workgroup = 16x16 pixels x all Cout, wave = 4 rows, K-step = 16 channels x a pair of taps).
+// conv_bf16x6.hip (one workgroup = 16x16 pixels x all Cout, K-step = 16 channels x a pair of taps); the wave tile is 8 rows x
+// 32 couts at Cout = 64 (WaveTile, split3.h) and the deferred tap of a tap pair crosses the group barrier in registers.
 //
-// K-step schedule (48 MFMAs at Cout = 64).  ONE weight register set, refilled in place from the L2-resident stream as
-// soon as the last MFMA that reads a split has issued:
-//   phase A: x0*w1 -> request the next w1     phase B1: x0*w0 -> read the next K-step's x0     phase B2: x1*w0 -> request w0
+// K-step schedule (48 MFMAs at Cout = 64):
+//   top: request the NEXT K-step's w0 into a second register set, read this K-step's x1 fragments, issue a slice of the halo
+//   phase A: x0*w1 -> request the next w1 into the same registers     phase B1: x0*w0 -> read the next K-step's x0
+//   phase B2: x1*w0 -> move the prefetched w0 over
+// Measurements, ablations and the variants that did not pay: DESIGN.md 4.1a.
 #include <type_traits>
 
 #include "pmp_kernels.h"
