@@ -277,7 +277,11 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv_h2_kernel(ConvX6Arg
     typedef GeoH<KH, KW> G;
     __shared__ u32x4 lds[2 * G::PIECES];
     const int tiles_x = a.W >> 4, tiles = tiles_x * (a.H >> 4);
-    const int n = blockIdx.x / tiles, t = blockIdx.x - n * tiles, ty = t / tiles_x, tx = t - ty * tiles_x;
+    // XCD-aware tile order: workgroup ids go round-robin over the 8 XCDs (each with its own L2), so consecutive ids would put
+    // neighbouring tiles - which share halo columns/rows - on different L2s.  Give every XCD a contiguous run of tiles instead.
+    int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    const int n = bid / tiles, t = bid - n * tiles, ty = t / tiles_x, tx = t - ty * tiles_x;
     typedef WaveTile<NT> WT;
     constexpr int RW = WT::RW, CW = WT::CW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, xl = lane & 15, g = lane >> 4;
