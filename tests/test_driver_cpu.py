@@ -41,3 +41,36 @@ def test_cli_flags_match_reference_defaults():
     a = D.build_parser().parse_args([])
     assert (a.jobID, a.inputDir, a.outDir, a.batchSize, a.startSeqID, a.seqNum) == ("0000", "/input/", "/output/", 200, 0, 22)
     assert a.ssRatio == 30
+
+
+def test_cli_extension_flags_default_to_reference_behaviour():
+    """Flags this driver adds are off by default; with them the output contract is unchanged (tests/test_gpu_parity.py)."""
+    a = D.build_parser().parse_args([])
+    assert a.binary is False and a.hostBlocks is False and a.strictBatch is False and a.device is None
+    assert a.qps == "22,27,32,37" and a.comps == "Luma,Chroma"
+    b = D.build_parser().parse_args(["--hostBlocks", "--strictBatch", "--binary", "--batchSize", "7", "--qps", "22", "--comps", "Chroma"])
+    assert b.hostBlocks and b.strictBatch and b.binary and b.batchSize == 7 and b.qps == "22" and b.comps == "Chroma"
+
+
+def test_tile_partition_maps_matches_the_text_layout_and_rejects_bad_arguments():
+    """pmp_tile_partition_maps (host code): frame matrices [F][R][C] in the order the VTM parser reads the text file."""
+    import numpy as np
+    from pmp_vvc_tip2023_amd import engine, _lib
+    rng = np.random.default_rng(5)
+    F, H, W = 2, 136, 200                                  # cropped to 128 x 192: 2 x 3 blocks per frame
+    n = F * (H // 64) * (W // 64)
+    hor = rng.integers(0, 2, (n, 16, 16), dtype=np.uint8); ver = rng.integers(0, 2, (n, 16, 16), dtype=np.uint8)
+    qt = rng.integers(0, 4, (n, 8, 8), dtype=np.uint8); dire = rng.integers(-1, 2, (n, 3, 16, 16)).astype(np.int8)
+    oh, ov, oq, od = engine.tile_partition_maps(F, H, W, hor, ver, qt, dire)
+    assert oh.shape == (F, 32, 48) and oq.shape == (F, 16, 24) and od.shape == (F, 3, 32, 48)
+    for f in range(F):
+        for br in range(2):
+            for bc in range(3):
+                b = (f * 2 + br) * 3 + bc
+                assert np.array_equal(oh[f, br * 16:(br + 1) * 16, bc * 16:(bc + 1) * 16], hor[b])
+                assert np.array_equal(ov[f, br * 16:(br + 1) * 16, bc * 16:(bc + 1) * 16], ver[b])
+                assert np.array_equal(oq[f, br * 8:(br + 1) * 8, bc * 8:(bc + 1) * 8], qt[b])
+                assert np.array_equal(od[f, :, br * 16:(br + 1) * 16, bc * 16:(bc + 1) * 16], dire[b])
+    lib = _lib.load()
+    assert lib.pmp_tile_partition_maps(F, H, W, None, None, None, None, None, None, None, None) == -1
+    assert b"pmp_tile_partition_maps" in lib.pmp_last_error(None)
