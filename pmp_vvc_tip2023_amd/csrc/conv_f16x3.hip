@@ -111,7 +111,7 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
     // W0DB: the next K-step's w0 fragments are requested at the TOP of a K-step into a second register set and moved over at
     // its end (8 v_mov) - a full K-step of lead for the split that is used last and needed first; taken from the second
     // halo staging set's registers.
-    constexpr bool W0DB = NT == 4;
+    constexpr bool W0DB = NT == 4 && G::TAPS <= 9;
     constexpr bool DEEP = G::TAPS <= 9 && NT == 4 && !W0DB;
     u32x4 r[G::NLD], rb[DEEP ? G::NLD : 1];
     StagePlanH<KH, KW> plan;
