@@ -396,7 +396,18 @@ static hipError_t launch_h2(hipStream_t s, const ConvX6Args &a)
     case 1: PMP_H2_LAUNCH(1); break;
     case 2: PMP_H2_LAUNCH(2); break;
     case 4:
-        if (KH == 3 && !a.x_sc && g_conv_variant >= 10) {   // timing-only ablation builds
+        if (KH == 5 && !a.x_sc && g_conv_variant >= 10) {   // timing-only ablation builds, 5x5
+            switch (g_conv_variant - 10) {
+            case 1: hipLaunchKernelGGL((conv_h2_kernel<5, 5, 4, false, 1>), dim3(grid), dim3(256), 0, s, a); break;
+            case 2: hipLaunchKernelGGL((conv_h2_kernel<5, 5, 4, false, 2>), dim3(grid), dim3(256), 0, s, a); break;
+            case 4: hipLaunchKernelGGL((conv_h2_kernel<5, 5, 4, false, 4>), dim3(grid), dim3(256), 0, s, a); break;
+            case 8: hipLaunchKernelGGL((conv_h2_kernel<5, 5, 4, false, 8>), dim3(grid), dim3(256), 0, s, a); break;
+            case 9: hipLaunchKernelGGL((conv_h2_kernel<5, 5, 4, false, 9>), dim3(grid), dim3(256), 0, s, a); break;
+            case 15: hipLaunchKernelGGL((conv_h2_kernel<5, 5, 4, false, 15>), dim3(grid), dim3(256), 0, s, a); break;
+            case 32: hipLaunchKernelGGL((conv_h2_kernel<5, 5, 4, false, 32>), dim3(grid), dim3(256), 0, s, a); break;
+            default: PMP_H2_LAUNCH(4); break;
+            }
+        } else if (KH == 3 && !a.x_sc && g_conv_variant >= 10) {   // timing-only ablation builds
             switch (g_conv_variant - 10) {
             case 1: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 1>), dim3(grid), dim3(256), 0, s, a); break;
             case 2: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 2>), dim3(grid), dim3(256), 0, s, a); break;

@@ -13,9 +13,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "ablate":
     shapes = [(256, 64, 64, 64, 64, 3)]
     if split == "f16x3": sys.argv[1] = "ablate_h2"
     abl = [0, 1, 2, 4, 8, 16, 32, 200, 128]      # bits: 1 staging, 2 weight loads, 4 x reads, 8 epilogue, 16 barrier, 32 staging from L2-resident addresses, 200 = LDS stores only, 128 = stamps
-if len(sys.argv) > 1 and sys.argv[1] == "ablate_h2":
+if len(sys.argv) > 1 and sys.argv[1] == "ablate5":
+    shapes = [(256, 64, 64, 64, 64, 5), (256, 64, 64, 32, 64, 5)]
+    abl = [0, 32, 0, 32, 1, 2, 4, 8, 9, 15]
+elif len(sys.argv) > 1 and sys.argv[1] == "ablate_h2":
     abl = [0, 32, 1, 2, 4, 8, 16, 9, 15, 128]   # 128: in-kernel stamps   # 16: epilogue without its stores (and a quarter of the conversions); 32: all halo requests with the first K-step (a real variant, not an ablation)
-elif len(sys.argv) > 1 and sys.argv[1] != "ablate":
+elif len(sys.argv) > 1 and sys.argv[1] not in ("ablate", "ablate5"):
     shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
 for ab in abl:
   eng.lib.pmp_debug_set_conv_variant(10 + ab if ab else 2)
