@@ -82,9 +82,9 @@ __device__ __forceinline__ void h2_stage_store(const StagePlanH<KH, KW> &p, u32x
     typedef GeoH<KH, KW> G;
 #pragma unroll
     for (int k = 0; k < G::NLD; ++k) {
-        const int i = threadIdx.x + k * 256;
+        const int i = min((int)threadIdx.x + k * 256, G::PIECES);   // pieces past the tile all land in one spare slot
         const u32x4 z = {0u, 0u, 0u, 0u};
-        if (i < G::PIECES) lds[i] = ((p.valid >> k) & 1u) ? r[k] : z;   // LDS image: [split][pixel][2 halves], linear
+        lds[i] = ((p.valid >> k) & 1u) ? r[k] : z;   // LDS image: [split][pixel][2 halves], linear
     }
 }
 
@@ -122,8 +122,12 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
     const f16x8 *wl = reinterpret_cast<const f16x8 *>(wpk) + lane + ch * CW * 64;
     const int last = paired ? (CB / 2) * G::TAPS - 1 : CB * G::NKS - 1;   // last K-step of the weight stream
     f16x8 w0[CW], w1[CW];   // ONE weight set, refilled in place as soon as the last MFMA that reads a split has issued
+    f16x8 w0n[W0DB ? CW : 1];   // W0DB: the K-step's w0 fragments land here and move to w0 between its phases A and B1
 #pragma unroll
-    for (int nt = 0; nt < CW; ++nt) { w0[nt] = wl[(0 * NT + nt) * 64]; w1[nt] = wl[(1 * NT + nt) * 64]; }
+    for (int nt = 0; nt < CW; ++nt) {
+        if (W0DB) w0n[nt] = wl[(0 * NT + nt) * 64]; else w0[nt] = wl[(0 * NT + nt) * 64];
+        w1[nt] = wl[(1 * NT + nt) * 64];
+    }
     __syncthreads();
     h2_stage_load<KH, KW>(plan, grp0, r);
     if (DEEP && paired) h2_stage_load<KH, KW>(plan, grp0 + grp_sz, reinterpret_cast<u32x4 (&)[G::NLD]>(rb));   // group 1 exists: CB is even
@@ -150,7 +154,7 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
         u32x4 (&rs)[G::NLD] = (DIST == 2 && MODE == 1) ? rbb : r;   // written to LDS at the end of this group (for group cb+1)
         constexpr bool more = !LAST;
         const unsigned short *nxt_grp = grp0 + (size_t)min(cb + DIST, CB - 1) * grp_sz;   // clamped (odd group in a deep pair before the tail)
-        const char *buf = reinterpret_cast<const char *>(lds + (cb & 1) * G::PIECES);
+        const char *buf = reinterpret_cast<const char *>(lds + (cb & 1) * G::BUF);
         auto xaddr = [&](int ks) -> const char * {   // in-group tap pair of K-step ks
             const int j = MODE == 2 ? ks - 1 : ks;
             int tA = 2 * j, tB = 2 * j + 1;
@@ -185,21 +189,11 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
 #pragma unroll
                 for (int m = 0; m < RW; ++m) x1[m] = *reinterpret_cast<const f16x8 *>(px + G::PLANE * 16 + m * G::TW * 32);
             }
-            // All of the group's halo requests go out with its first K-step: the counter that orders vector-memory
-            // operations is in-order, so a weight fragment requested after an HBM load cannot be used before that load has
-            // landed - one such wait per group instead of one per K-step.
-            if (!(ABL & 1) && FETCH) {
-                if (ABL & 32) { if (ks == 0) h2_stage_load<KH, KW>(plan, nxt_grp, rl); }
-                else h2_stage_load<KH, KW>(plan, nxt_grp, rl, ks * PER, (ks + 1) * PER);
-            }
             const f16x8 *wf = wl + (size_t)min(stream, last) * (2 * NT * 64);   // next K-step's fragments (L2-resident)
-            f16x8 w0n[CW];
-            if (W0DB && !(ABL & 2)) {
-#pragma unroll
-                for (int nt = 0; nt < CW; ++nt) w0n[nt] = wf[(0 * NT + nt) * 64];
-            }
             __builtin_amdgcn_sched_barrier(0);
-            // phase A: x0*w1, then w1 is free for the next K-step's fragments
+            // phase A: x0*w1, then w1 is free for the next K-step's fragments.  No vector-memory request precedes it inside
+            // the K-step: hipcc loses the exact outstanding-load count across the group loop's back edge and waits for
+            // vmcnt(0) at a group's first use of a weight fragment - which must not cover a halo request issued just before.
 #pragma unroll
             for (int m = 0; m < RW; ++m)
 #pragma unroll
@@ -208,6 +202,19 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
             if (!(ABL & 2)) {
 #pragma unroll
                 for (int nt = 0; nt < CW; ++nt) w1[nt] = wf[(1 * NT + nt) * 64];
+                if (W0DB) {   // this K-step's w0 was requested a K-step ago; its successor goes out at once
+#pragma unroll
+                    for (int nt = 0; nt < CW; ++nt) w0[nt] = w0n[nt];
+#pragma unroll
+                    for (int nt = 0; nt < CW; ++nt) w0n[nt] = wf[(0 * NT + nt) * 64];
+                }
+            }
+            // The halo requests follow the weight requests: the counter that orders vector-memory operations is in-order, so
+            // a weight fragment requested after an HBM load cannot be used before that load has landed.  Here the next such
+            // fragment is the w1 request of the NEXT K-step, used two K-steps from now.
+            if (!(ABL & 1) && FETCH) {
+                if (ABL & 32) { if (ks == 0) h2_stage_load<KH, KW>(plan, nxt_grp, rl); }
+                else h2_stage_load<KH, KW>(plan, nxt_grp, rl, ks * PER, (ks + 1) * PER);
             }
             __builtin_amdgcn_sched_barrier(0);
             // phase B1: x0*w0, then x0 is free for the next K-step's pixels
@@ -228,9 +235,9 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
 #pragma unroll
                 for (int nt = 0; nt < CW; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[nt], x1[m], acc[m][nt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (!(ABL & 2)) {
+            if (!W0DB && !(ABL & 2)) {
 #pragma unroll
-                for (int nt = 0; nt < CW; ++nt) w0[nt] = W0DB ? w0n[nt] : wf[(0 * NT + nt) * 64];
+                for (int nt = 0; nt < CW; ++nt) w0[nt] = wf[(0 * NT + nt) * 64];
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -245,7 +252,7 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
         }
         if (ABL & 128) { const unsigned long long t = h2_stamp(); t_k += t - tmark; tmark = t; }
         // the store goes to the buffer nobody reads during this group (the deferred tap travels in registers)
-        if (more && !(ABL & 1)) h2_stage_store<KH, KW>(plan, lds + ((cb + 1) & 1) * G::PIECES, rs);
+        if (more && !(ABL & 1)) h2_stage_store<KH, KW>(plan, lds + ((cb + 1) & 1) * G::BUF, rs);
         if (ABL & 128) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t = h2_stamp(); t_s += t - tmark; tmark = t; }
         __syncthreads();
         if (ABL & 128) { const unsigned long long t = h2_stamp(); t_b += t - tmark; tmark = t; }
@@ -275,7 +282,7 @@ template <int KH, int KW, int NT, bool SC, int ABL = 0>
 __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv_h2_kernel(ConvX6Args a)
 {
     typedef GeoH<KH, KW> G;
-    __shared__ u32x4 lds[2 * G::PIECES];
+    __shared__ u32x4 lds[2 * G::BUF];
     const int tiles_x = a.W >> 4, tiles = tiles_x * (a.H >> 4);
     // XCD-aware tile order: workgroup ids go round-robin over the 8 XCDs (each with its own L2), so consecutive ids would put
     // neighbouring tiles - which share halo columns/rows - on different L2s.  Give every XCD a contiguous run of tiles instead.

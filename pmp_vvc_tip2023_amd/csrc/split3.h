@@ -94,6 +94,9 @@ struct GeoH {
     static constexpr int PLANE = TH * TW * 2;            // 16-B pieces per split plane (32 B per pixel)
     static constexpr int PIECES = 2 * PLANE;             // per buffer
     static constexpr int NLD = (PIECES + 255) / 256;
+    static constexpr int BUF = PIECES + 1;               // pieces reserved per LDS buffer: one spare slot, so that every staging thread
+                                                         // stores all NLD of its pieces unconditionally (a conditional store lets hipcc
+                                                         // sink the global load into the branch, next to its use, and wait for it there)
 };
 
 // Wave tile: RW rows x CW cout groups of the workgroup's 16 rows x NT groups (4 waves).  At Cout >= 32 a wave takes 8 rows
