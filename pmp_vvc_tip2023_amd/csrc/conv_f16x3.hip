@@ -77,11 +77,13 @@ __device__ __forceinline__ void h2_stage_load(const StagePlanH<KH, KW> &p, const
 }
 
 template <int KH, int KW>
-__device__ __forceinline__ void h2_stage_store(const StagePlanH<KH, KW> &p, u32x4 *lds, const u32x4 (&r)[GeoH<KH, KW>::NLD])
+__device__ __forceinline__ void h2_stage_store(const StagePlanH<KH, KW> &p, u32x4 *lds, const u32x4 (&r)[GeoH<KH, KW>::NLD],
+                                               int k0 = 0, int k1 = 1 << 20)
 {
     typedef GeoH<KH, KW> G;
 #pragma unroll
     for (int k = 0; k < G::NLD; ++k) {
+        if (k < k0 || k >= k1) continue;
         const int i = min((int)threadIdx.x + k * 256, G::PIECES);   // pieces past the tile all land in one spare slot
         const u32x4 z = {0u, 0u, 0u, 0u};
         lds[i] = ((p.valid >> k) & 1u) ? r[k] : z;   // LDS image: [split][pixel][2 halves], linear
@@ -108,10 +110,9 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
     // latency here is longer than one 3x3 group).  Plain mode keeps one set and a distance of one group.
     // 5x5 groups (12.5 K-steps) outlast the HBM latency on their own; the Cout <= 32 kernels are latency-bound small layers
     // that gain more from a third resident workgroup (168 VGPRs) than from the second staging set
-    // W0DB: the next K-step's w0 fragments are requested at the TOP of a K-step into a second register set and moved over at
-    // its end (8 v_mov) - a full K-step of lead for the split that is used last and needed first; taken from the second
-    // halo staging set's registers.
-    constexpr bool W0DB = NT == 4 && G::TAPS <= 9;
+    // W0DB: a K-step's w0 fragments are requested one K-step ahead into a second register set and moved over between its
+    // phases A and B1 (8 v_mov) - a full K-step of lead for the split that is used last and needed first.
+    constexpr bool W0DB = NT == 4;
     constexpr bool DEEP = G::TAPS <= 9 && NT == 4 && !W0DB;
     u32x4 r[G::NLD], rb[DEEP ? G::NLD : 1];
     StagePlanH<KH, KW> plan;
@@ -148,6 +149,8 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
         constexpr int NK = MODE == 0 ? G::NKS : (MODE == 1 ? (G::TAPS - 1) / 2 : (G::TAPS - 1) / 2 + 1);
         constexpr int PER = (G::NLD + (NK > 0 ? NK : 1) - 1) / (NK > 0 ? NK : 1);   // staging loads issued per K-step
         constexpr int DIST = (MODE == 0 || !DEEP) ? 1 : 2;   // groups between a halo request and its LDS store
+        constexpr int LAG = G::TAPS > 9 ? 3 : 2;             // K-steps between a halo slice's request and its LDS store
+        constexpr bool ROLL = DIST == 1 && !(ABL & 64);
         constexpr bool FETCH = TAIL < (DIST == 2 ? 1 : 2);    // is there a group cb+DIST to request
         u32x4 (&rbb)[G::NLD] = reinterpret_cast<u32x4 (&)[G::NLD]>(rb);
         u32x4 (&rl)[G::NLD] = (DIST == 2 && MODE == 2) ? rbb : r;   // requested during this group
@@ -216,6 +219,9 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
                 if (ABL & 32) { if (ks == 0) h2_stage_load<KH, KW>(plan, nxt_grp, rl); }
                 else h2_stage_load<KH, KW>(plan, nxt_grp, rl, ks * PER, (ks + 1) * PER);
             }
+            // ... and the slice requested LAG K-steps ago goes to the partner LDS buffer, which nobody reads during this group
+            if (ROLL && more && !(ABL & 1) && ks >= LAG)
+                h2_stage_store<KH, KW>(plan, lds + ((cb + 1) & 1) * G::BUF, rs, (ks - LAG) * PER, (ks - LAG + 1) * PER);
             __builtin_amdgcn_sched_barrier(0);
             // phase B1: x0*w0, then x0 is free for the next K-step's pixels
 #pragma unroll
@@ -252,7 +258,8 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
         }
         if (ABL & 128) { const unsigned long long t = h2_stamp(); t_k += t - tmark; tmark = t; }
         // the store goes to the buffer nobody reads during this group (the deferred tap travels in registers)
-        if (more && !(ABL & 1)) h2_stage_store<KH, KW>(plan, lds + ((cb + 1) & 1) * G::BUF, rs);
+        if (more && !(ABL & 1))
+            h2_stage_store<KH, KW>(plan, lds + ((cb + 1) & 1) * G::BUF, rs, ROLL && NK > LAG ? (NK - LAG) * PER : 0);
         if (ABL & 128) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t = h2_stamp(); t_s += t - tmark; tmark = t; }
         __syncthreads();
         if (ABL & 128) { const unsigned long long t = h2_stamp(); t_b += t - tmark; tmark = t; }
