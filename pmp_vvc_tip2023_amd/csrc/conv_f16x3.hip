@@ -90,10 +90,19 @@ __device__ __forceinline__ void h2_stage_store(const StagePlanH<KH, KW> &p, u32x
     }
 }
 
-template <int KH, int KW, int NT, int ABL = 0>
+// State that outlives one tile in the persistent kernel (CHAIN): the weight fragments of the next K-step - the stream wraps
+// around to the first K-step at the end of a tile - and the staging plan of the tile whose first halo group is in LDS.
+template <int KH, int KW, int NT>
+struct H2Carry {
+    f16x8 w0[WaveTile<NT>::CW], w1[WaveTile<NT>::CW], w0n[WaveTile<NT>::CW];
+    StagePlanH<KH, KW> plan;
+};
+
+template <int KH, int KW, int NT, int ABL = 0, bool CHAIN = false>
 __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__ x, size_t plane_stride,
                                               const unsigned short *__restrict__ wpk, int C, int H, int W, int n, int ty,
-                                              int tx, u32x4 *lds, f32x4 (&acc)[WaveTile<NT>::RW][WaveTile<NT>::CW], unsigned long long *dbg = nullptr)
+                                              int tx, u32x4 *lds, f32x4 (&acc)[WaveTile<NT>::RW][WaveTile<NT>::CW],
+                                              unsigned long long *dbg, H2Carry<KH, KW, NT> &c, bool first, int n2, int ty2, int tx2)
 {
     unsigned long long t_pro = 0, t_k = 0, t_s = 0, t_b = 0, tmark = 0;   // diagnostic accumulators (ABL & 128)
     if (ABL & 128) tmark = h2_stamp();
@@ -115,25 +124,27 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
     constexpr bool W0DB = NT == 4;
     constexpr bool DEEP = G::TAPS <= 9 && NT == 4 && !W0DB;
     u32x4 r[G::NLD], rb[DEEP ? G::NLD : 1];
-    StagePlanH<KH, KW> plan;
-    h2_plan<KH, KW>(plan, plane_stride, H, W, ty, tx);
+    StagePlanH<KH, KW> &plan = c.plan;
     // Tap pairing as in conv_bf16x6.hip: mode 0 plain (last pair zero-padded), mode 1 even group of a pair (its last tap
     // is deferred and carried in registers), mode 2 odd group (first K-step = the deferred tap + its own last tap).
     const bool paired = (CB & 1) == 0 && (G::TAPS & 1);
     const f16x8 *wl = reinterpret_cast<const f16x8 *>(wpk) + lane + ch * CW * 64;
     const int last = paired ? (CB / 2) * G::TAPS - 1 : CB * G::NKS - 1;   // last K-step of the weight stream
-    f16x8 w0[CW], w1[CW];   // ONE weight set, refilled in place as soon as the last MFMA that reads a split has issued
-    f16x8 w0n[W0DB ? CW : 1];   // W0DB: the K-step's w0 fragments land here and move to w0 between its phases A and B1
+    f16x8 (&w0)[CW] = c.w0, (&w1)[CW] = c.w1;   // ONE weight set, refilled in place as soon as the last MFMA that reads a split has issued
+    f16x8 (&w0n)[CW] = c.w0n;                  // W0DB: the K-step's w0 fragments land here and move to w0 between its phases A and B1
+    if (!CHAIN || first) {   // a chained tile finds its weights in the carry and its first halo group in LDS buffer 0
+        h2_plan<KH, KW>(plan, plane_stride, H, W, ty, tx);
 #pragma unroll
-    for (int nt = 0; nt < CW; ++nt) {
-        if (W0DB) w0n[nt] = wl[(0 * NT + nt) * 64]; else w0[nt] = wl[(0 * NT + nt) * 64];
-        w1[nt] = wl[(1 * NT + nt) * 64];
+        for (int nt = 0; nt < CW; ++nt) {
+            if (W0DB) w0n[nt] = wl[(0 * NT + nt) * 64]; else w0[nt] = wl[(0 * NT + nt) * 64];
+            w1[nt] = wl[(1 * NT + nt) * 64];
+        }
+        __syncthreads();
+        h2_stage_load<KH, KW>(plan, grp0, r);
+        if (DEEP && paired) h2_stage_load<KH, KW>(plan, grp0 + grp_sz, reinterpret_cast<u32x4 (&)[G::NLD]>(rb));   // group 1 exists: CB is even
+        h2_stage_store<KH, KW>(plan, lds, r);
+        __syncthreads();
     }
-    __syncthreads();
-    h2_stage_load<KH, KW>(plan, grp0, r);
-    if (DEEP && paired) h2_stage_load<KH, KW>(plan, grp0 + grp_sz, reinterpret_cast<u32x4 (&)[G::NLD]>(rb));   // group 1 exists: CB is even
-    h2_stage_store<KH, KW>(plan, lds, r);
-    __syncthreads();
     if (ABL & 128) { const unsigned long long t = h2_stamp(); t_pro = t - tmark; tmark = t; }
     // ABL: timing-only builds (tools/conv_x6_bench.py h2 ablate): 1 no halo staging, 2 no weight refills, 4 no fragment reads, 8 no epilogue
     const int pb = ((rh * RW * G::TW + xl) * 2 + (g & 1)) * 16;   // bytes inside a split plane, tap (0,0)
@@ -151,12 +162,16 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
         constexpr int DIST = (MODE == 0 || !DEEP) ? 1 : 2;   // groups between a halo request and its LDS store
         constexpr int LAG = G::TAPS > 9 ? 3 : 2;             // K-steps between a halo slice's request and its LDS store
         constexpr bool ROLL = DIST == 1 && !(ABL & 64);
-        constexpr bool FETCH = TAIL < (DIST == 2 ? 1 : 2);    // is there a group cb+DIST to request
+        constexpr bool CHAINF = CHAIN && LAST;                // persistent kernel: the last group requests the NEXT tile's first group
+        constexpr bool FETCH = CHAINF || TAIL < (DIST == 2 ? 1 : 2);    // is there a group cb+DIST to request
         u32x4 (&rbb)[G::NLD] = reinterpret_cast<u32x4 (&)[G::NLD]>(rb);
         u32x4 (&rl)[G::NLD] = (DIST == 2 && MODE == 2) ? rbb : r;   // requested during this group
         u32x4 (&rs)[G::NLD] = (DIST == 2 && MODE == 1) ? rbb : r;   // written to LDS at the end of this group (for group cb+1)
-        constexpr bool more = !LAST;
-        const unsigned short *nxt_grp = grp0 + (size_t)min(cb + DIST, CB - 1) * grp_sz;   // clamped (odd group in a deep pair before the tail)
+        constexpr bool more = !LAST || CHAINF;
+        // the plan's last use for this tile was the request of this group during the previous one
+        if (CHAINF) h2_plan<KH, KW>(plan, plane_stride, H, W, ty2, tx2);
+        const unsigned short *nxt_grp = CHAINF ? x + (size_t)n2 * CB * grp_sz
+                                               : grp0 + (size_t)min(cb + DIST, CB - 1) * grp_sz;   // clamped (odd group in a deep pair before the tail)
         const char *buf = reinterpret_cast<const char *>(lds + (cb & 1) * G::BUF);
         auto xaddr = [&](int ks) -> const char * {   // in-group tap pair of K-step ks
             const int j = MODE == 2 ? ks - 1 : ks;
@@ -192,7 +207,8 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
 #pragma unroll
                 for (int m = 0; m < RW; ++m) x1[m] = *reinterpret_cast<const f16x8 *>(px + G::PLANE * 16 + m * G::TW * 32);
             }
-            const f16x8 *wf = wl + (size_t)min(stream, last) * (2 * NT * 64);   // next K-step's fragments (L2-resident)
+            // next K-step's fragments (L2-resident); the persistent kernel wraps around to the next tile's first K-step
+            const f16x8 *wf = wl + (size_t)(CHAIN ? (stream > last ? 0 : stream) : min(stream, last)) * (2 * NT * 64);
             __builtin_amdgcn_sched_barrier(0);
             // phase A: x0*w1, then w1 is free for the next K-step's fragments.  No vector-memory request precedes it inside
             // the K-step: hipcc loses the exact outstanding-load count across the group loop's back edge and waits for
@@ -285,6 +301,9 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
     if ((ABL & 128) && dbg && threadIdx.x == 0) { dbg[0] = t_pro; dbg[1] = t_k; dbg[2] = t_s; dbg[3] = t_b; }
 }
 
+template <int NT, int ABL>
+__device__ __forceinline__ void h2_epilogue(const ConvX6Args &a, f32x4 (&acc)[WaveTile<NT>::RW][WaveTile<NT>::CW], int n, int ty, int tx);
+
 template <int KH, int KW, int NT, bool SC, int ABL = 0>
 __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv_h2_kernel(ConvX6Args a)
 {
@@ -298,8 +317,6 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv_h2_kernel(ConvX6Arg
     const int n = bid / tiles, t = bid - n * tiles, ty = t / tiles_x, tx = t - ty * tiles_x;
     typedef WaveTile<NT> WT;
     constexpr int RW = WT::RW, CW = WT::CW;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, xl = lane & 15, g = lane >> 4;
-    const int rh = wave % WT::RSPLIT, ch = wave / WT::RSPLIT;
 
     f32x4 acc[RW][CW];
 #pragma unroll
@@ -307,12 +324,66 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv_h2_kernel(ConvX6Arg
 #pragma unroll
         for (int nt = 0; nt < CW; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    const unsigned long long t_begin = (ABL & 128) ? h2_stamp() : 0;
+    {
+        H2Carry<KH, KW, NT> carry;
+        h2_accumulate<KH, KW, NT, ABL>(a.x, a.x_stride, a.w, a.Cin, a.H, a.W, n, ty, tx, lds, acc,
+                                       a.dbg ? a.dbg + (size_t)blockIdx.x * 8 : nullptr, carry, true, n, ty, tx);
+    }
+    const unsigned long long t_acc = (ABL & 128) ? h2_stamp() : 0;
+    if (SC) {
+        H2Carry<1, 1, NT> carry;
+        h2_accumulate<1, 1, NT, 0>(a.x_sc, a.sc_stride, a.w_sc, a.Csc, a.H, a.W, n, ty, tx, lds, acc, nullptr, carry, true, n, ty, tx);
+    }
+    h2_epilogue<NT, ABL>(a, acc, n, ty, tx);
+    if ((ABL & 128) && a.dbg && threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // include the store acknowledgements in the epilogue span
+        const unsigned long long t_end = h2_stamp();
+        unsigned long long *d = a.dbg + (size_t)blockIdx.x * 8;
+        d[4] = t_acc - t_begin; d[5] = t_end - t_acc; d[6] = t_begin; d[7] = t_end;
+    }
+}
+
+// Persistent form of the same kernel for the Cout = 64 layers without a shortcut source and with an even group count: 2
+// workgroups per CU walk the tiles of their XCD's contiguous share.  The last channel group of a tile requests the first
+// group of the workgroup's next tile and the weight stream wraps around, so a tile starts at its first MFMA: no dispatch
+// gap, no prologue (halo round trip + barriers) between tiles.  It is NOT faster (the layer is bound by what the K-loop and
+// the epilogue move, not by the gaps), so launch_h2 only takes it on request.
+template <int KH, int KW, int NT, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void conv_h2_persist_kernel(ConvX6Args a)
+{
+    typedef GeoH<KH, KW> G;
+    __shared__ u32x4 lds[2 * G::BUF];
+    typedef WaveTile<NT> WT;
+    constexpr int RW = WT::RW, CW = WT::CW;
+    const int tiles_x = a.W >> 4, tiles = tiles_x * (a.H >> 4);
+    const int per_xcd = (a.N * tiles) >> 3, xcd = blockIdx.x & 7, S = gridDim.x >> 3;   // launch_h2 guarantees the divisibility
+    H2Carry<KH, KW, NT> carry;
+    bool first = true;
+    for (int t = blockIdx.x >> 3; t < per_xcd; t += S) {
+        const int tile = xcd * per_xcd + t, tile2 = t + S < per_xcd ? tile + S : tile;   // the last tile re-requests itself (unused)
+        const int n = tile / tiles, tt = tile - n * tiles, ty = tt / tiles_x, tx = tt - ty * tiles_x;
+        const int n2 = tile2 / tiles, tt2 = tile2 - n2 * tiles, ty2 = tt2 / tiles_x, tx2 = tt2 - ty2 * tiles_x;
+        f32x4 acc[RW][CW];
+#pragma unroll
+        for (int m = 0; m < RW; ++m)
+#pragma unroll
+            for (int nt = 0; nt < CW; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        h2_accumulate<KH, KW, NT, ABL, true>(a.x, a.x_stride, a.w, a.Cin, a.H, a.W, n, ty, tx, lds, acc, nullptr, carry, first, n2, ty2, tx2);
+        first = false;
+        h2_epilogue<NT, ABL>(a, acc, n, ty, tx);
+    }
+}
+
+template <int NT, int ABL>
+__device__ __forceinline__ void h2_epilogue(const ConvX6Args &a, f32x4 (&acc)[WaveTile<NT>::RW][WaveTile<NT>::CW], int n, int ty, int tx)
+{
+    typedef WaveTile<NT> WT;
+    constexpr int RW = WT::RW, CW = WT::CW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, xl = lane & 15, g = lane >> 4;
+    const int rh = wave % WT::RSPLIT, ch = wave / WT::RSPLIT;
     const int H = a.H, W = a.W;
     const size_t grp = (size_t)H * W * 16;
-    const unsigned long long t_begin = (ABL & 128) ? h2_stamp() : 0;
-    h2_accumulate<KH, KW, NT, ABL>(a.x, a.x_stride, a.w, a.Cin, a.H, a.W, n, ty, tx, lds, acc, a.dbg ? a.dbg + (size_t)blockIdx.x * 8 : nullptr);
-    const unsigned long long t_acc = (ABL & 128) ? h2_stamp() : 0;
-    if (SC) h2_accumulate<1, 1, NT, 0>(a.x_sc, a.sc_stride, a.w_sc, a.Csc, a.H, a.W, n, ty, tx, lds, acc);
 
     const float inv_scale = a.out_scale;
     // element offset of (row 0, cout group 0) of this wave inside a [n][NT][H][W][16] tensor: < 2^32 for every chunk size
@@ -390,12 +461,6 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv_h2_kernel(ConvX6Arg
             }
         }
     }
-    if ((ABL & 128) && a.dbg && threadIdx.x == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // include the store acknowledgements in the epilogue span
-        const unsigned long long t_end = h2_stamp();
-        unsigned long long *d = a.dbg + (size_t)blockIdx.x * 8;
-        d[4] = t_acc - t_begin; d[5] = t_end - t_acc; d[6] = t_begin; d[7] = t_end;
-    }
 }
 
 template <int KH, int KW>
@@ -434,6 +499,10 @@ static hipError_t launch_h2(hipStream_t s, const ConvX6Args &a)
             case 128: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 128>), dim3(grid), dim3(256), 0, s, a); break;
             default: PMP_H2_LAUNCH(4); break;
             }
+        } else if (KH > 1 && !a.x_sc && !((a.Cin >> 4) & 1) && !(grid & 7) && g_conv_variant == 4) {
+            // persistent form (opt-in, PMP_CONV_VARIANT=4): 2 workgroups per CU, 64 per XCD.  Measured 2 % SLOWER than one
+            // workgroup per tile on the 1024-block luma step: kept as a tested A/B variant, not the default.
+            hipLaunchKernelGGL((conv_h2_persist_kernel<KH, KW, 4>), dim3(8 * min(64, grid >> 3)), dim3(256), 0, s, a);
         } else {
             PMP_H2_LAUNCH(4);
         }

@@ -124,6 +124,26 @@ def test_f16x3_saturates_instead_of_overflowing(g1):
         e2.close()
 
 
+def test_f16x3_conv_variants_agree(g1):
+    """The opt-in persistent form of the f16x3 convolution (PMP_CONV_VARIANT=4, conv_f16x3.hip) must give the logits of
+    the default one-workgroup-per-tile form bit for bit: same K order, same accumulators."""
+    from pmp_vvc_tip2023_amd import engine
+    e2 = engine.Engine(0)
+    try:
+        e2.set_precision("f16x3")
+        y = np.concatenate([g1["block_y"]] * 8)              # 128 blocks: several tiles per persistent workgroup at 64x64
+        ref = e2.inference_pre_QBD("Luma", 22, y)
+        assert e2.lib.pmp_debug_set_conv_variant(4) == 0
+        try:
+            got = e2.inference_pre_QBD("Luma", 22, y)
+        finally:
+            e2.lib.pmp_debug_set_conv_variant(2)
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b)
+    finally:
+        e2.close()
+
+
 # ------------------------------------------------------------------------------------------------ post-processing
 def test_map_to_partition_bit_exact_vs_reference_golden(eng, oracle_lib):
     """G3 through pmp_postprocess.  The ABI applies eli_structual_error first (as seq_post_process does), so golden
