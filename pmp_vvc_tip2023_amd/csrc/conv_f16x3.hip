@@ -161,7 +161,7 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
         constexpr int PER = (G::NLD + (NK > 0 ? NK : 1) - 1) / (NK > 0 ? NK : 1);   // staging loads issued per K-step
         constexpr int DIST = (MODE == 0 || !DEEP) ? 1 : 2;   // groups between a halo request and its LDS store
         constexpr int LAG = G::TAPS > 9 ? 3 : 2;             // K-steps between a halo slice's request and its LDS store
-        constexpr bool ROLL = DIST == 1 && !(ABL & 64);
+        constexpr bool ROLL = DIST == 1;
         constexpr bool CHAINF = CHAIN && LAST;                // persistent kernel: the last group requests the NEXT tile's first group
         constexpr bool FETCH = CHAINF || TAIL < (DIST == 2 ? 1 : 2);    // is there a group cb+DIST to request
         u32x4 (&rbb)[G::NLD] = reinterpret_cast<u32x4 (&)[G::NLD]>(rb);
@@ -314,7 +314,8 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv_h2_kernel(ConvX6Arg
     // neighbouring tiles - which share halo columns/rows - on different L2s.  Give every XCD a contiguous run of tiles instead.
     int bid = blockIdx.x;
     if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
-    const int n = bid / tiles, t = bid - n * tiles, ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int n0 = bid / tiles, t = bid - n0 * tiles, ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int n = (ABL & 64) ? 0 : n0;   // timing-only build: every block's addresses collapse onto block 0 (L2-resident working set)
     typedef WaveTile<NT> WT;
     constexpr int RW = WT::RW, CW = WT::CW;
 
@@ -496,6 +497,7 @@ static hipError_t launch_h2(hipStream_t s, const ConvX6Args &a)
             case 15: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 15>), dim3(grid), dim3(256), 0, s, a); break;
             case 16: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 16>), dim3(grid), dim3(256), 0, s, a); break;
             case 32: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 32>), dim3(grid), dim3(256), 0, s, a); break;
+            case 64: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 64>), dim3(grid), dim3(256), 0, s, a); break;
             case 128: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 128>), dim3(grid), dim3(256), 0, s, a); break;
             default: PMP_H2_LAUNCH(4); break;
             }

@@ -17,7 +17,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "ablate5":
     shapes = [(256, 64, 64, 64, 64, 5), (256, 64, 64, 32, 64, 5)]
     abl = [0, 32, 0, 32, 1, 2, 4, 8, 9, 15]
 elif len(sys.argv) > 1 and sys.argv[1] == "ablate_h2":
-    abl = [0, 32, 1, 2, 4, 8, 16, 9, 15, 128]   # 128: in-kernel stamps   # 16: epilogue without its stores (and a quarter of the conversions); 32: all halo requests with the first K-step (a real variant, not an ablation)
+    abl = [0, 32, 64, 1, 2, 4, 8, 16, 9, 15, 128]   # 128: in-kernel stamps   # 64: all blocks read and write block 0's addresses (L2-resident working set: what HBM costs); 16: epilogue without its stores (and a quarter of the conversions); 32: all halo requests with the first K-step (a real variant, not an ablation)
 elif len(sys.argv) > 1 and sys.argv[1] not in ("ablate", "ablate5"):
     shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
 for ab in abl:
