@@ -98,7 +98,7 @@ struct H2Carry {
     StagePlanH<KH, KW> plan;
 };
 
-template <int KH, int KW, int NT, int ABL = 0, bool CHAIN = false>
+template <int KH, int KW, int NT, int ABL = 0, bool CHAIN = false, bool LEAN = false>
 __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__ x, size_t plane_stride,
                                               const unsigned short *__restrict__ wpk, int C, int H, int W, int n, int ty,
                                               int tx, u32x4 *lds, f32x4 (&acc)[WaveTile<NT>::RW][WaveTile<NT>::CW],
@@ -180,96 +180,151 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
             const int oA = ((tA / KW) * G::TW + tA % KW) * 32, oB = ((tB / KW) * G::TW + tB % KW) * 32;
             return buf + (tapsel ? oB : oA) + pb;
         };
-        if (NK == 0) {   // 1x1 source, even group: nothing to compute yet, only fetch the partner group
-            if (!(ABL & 1) && FETCH) h2_stage_load<KH, KW>(plan, nxt_grp, rl);
-        } else if (MODE == 2) {
-            // cross-group pair: lanes g < 2 still hold the even group's last tap (picked up before the barrier that ended
-            // it - that buffer is being overwritten by now), lanes g >= 2 read this group's last tap
-            if (g >= 2) {
+        if constexpr (LEAN) {
+            // 168-VGPR form for a third workgroup per CU: pixel fragments of 4 rows at a time, single-buffered (the other two
+            // waves of the SIMD cover the LDS round trip), and the cross-group tap read from the partner buffer instead of
+            // carried in 64 registers - with a barrier before that buffer's first rolling store.
+            const char *part = reinterpret_cast<const char *>(lds + ((cb + 1) & 1) * G::BUF);
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                asm volatile("" : "+v"(tapsel));
+                const char *px = (MODE == 2 && ks == 0) ? (g < 2 ? part : buf) + O_LAST + pb : xaddr(ks);
+                ++stream;
+                const f16x8 *wf = wl + (size_t)(CHAIN ? (stream > last ? 0 : stream) : min(stream, last)) * (2 * NT * 64);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f16x8 xa[RW / 2], xb[RW / 2];
+#pragma unroll
+                    for (int m = 0; m < RW / 2; ++m) {
+                        xa[m] = *reinterpret_cast<const f16x8 *>(px + (h * (RW / 2) + m) * G::TW * 32);
+                        xb[m] = *reinterpret_cast<const f16x8 *>(px + G::PLANE * 16 + (h * (RW / 2) + m) * G::TW * 32);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < RW / 2; ++m)
+#pragma unroll
+                        for (int nt = 0; nt < CW; ++nt)
+                            acc[h * (RW / 2) + m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[nt], xa[m], acc[h * (RW / 2) + m][nt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (h == 0) {
+#pragma unroll
+                        for (int nt = 0; nt < CW; ++nt) w0[nt] = w0n[nt];
+#pragma unroll
+                        for (int nt = 0; nt < CW; ++nt) w0n[nt] = wf[(0 * NT + nt) * 64];
+                        if (FETCH) h2_stage_load<KH, KW>(plan, nxt_grp, rl, ks * PER, (ks + 1) * PER);
+                        if (more && ks >= LAG)
+                            h2_stage_store<KH, KW>(plan, lds + ((cb + 1) & 1) * G::BUF, rs, (ks - LAG) * PER, (ks - LAG + 1) * PER);
+                    } else {
+#pragma unroll
+                        for (int nt = 0; nt < CW; ++nt) w1[nt] = wf[(1 * NT + nt) * 64];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < RW / 2; ++m)
+#pragma unroll
+                        for (int nt = 0; nt < CW; ++nt)
+                            acc[h * (RW / 2) + m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[nt], xa[m], acc[h * (RW / 2) + m][nt], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < RW / 2; ++m)
+#pragma unroll
+                        for (int nt = 0; nt < CW; ++nt)
+                            acc[h * (RW / 2) + m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[nt], xb[m], acc[h * (RW / 2) + m][nt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (MODE == 2 && ks == 0) h2_lds_barrier();   // every wave has read the partner buffer's last tap
+            }
+        } else {
+            if (NK == 0) {   // 1x1 source, even group: nothing to compute yet, only fetch the partner group
+                if (!(ABL & 1) && FETCH) h2_stage_load<KH, KW>(plan, nxt_grp, rl);
+            } else if (MODE == 2) {
+                // cross-group pair: lanes g < 2 still hold the even group's last tap (picked up before the barrier that ended
+                // it - that buffer is being overwritten by now), lanes g >= 2 read this group's last tap
+                if (g >= 2) {
+                    const char *pl = buf + O_LAST + pb;
+#pragma unroll
+                    for (int m = 0; m < RW; ++m) {
+                        x0[m] = *reinterpret_cast<const f16x8 *>(pl + m * G::TW * 32);
+                        x1[m] = *reinterpret_cast<const f16x8 *>(pl + G::PLANE * 16 + m * G::TW * 32);
+                    }
+                }
+            } else {
+                const char *p0x = xaddr(0);
+#pragma unroll
+                for (int m = 0; m < RW; ++m) x0[m] = *reinterpret_cast<const f16x8 *>(p0x + m * G::TW * 32);
+            }
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                asm volatile("" : "+v"(tapsel));   // keeps hipcc from hoisting every K-step's tap offset out of the group loop
+                const char *px = (MODE == 2 && ks == 0) ? buf : xaddr(ks);
+                ++stream;
+                if ((!(ABL & 4) || ks == 0) && !(MODE == 2 && ks == 0)) {
+#pragma unroll
+                    for (int m = 0; m < RW; ++m) x1[m] = *reinterpret_cast<const f16x8 *>(px + G::PLANE * 16 + m * G::TW * 32);
+                }
+                // next K-step's fragments (L2-resident); the persistent kernel wraps around to the next tile's first K-step
+                const f16x8 *wf = wl + (size_t)(CHAIN ? (stream > last ? 0 : stream) : min(stream, last)) * (2 * NT * 64);
+                __builtin_amdgcn_sched_barrier(0);
+                // phase A: x0*w1, then w1 is free for the next K-step's fragments.  No vector-memory request precedes it inside
+                // the K-step: hipcc loses the exact outstanding-load count across the group loop's back edge and waits for
+                // vmcnt(0) at a group's first use of a weight fragment - which must not cover a halo request issued just before.
+#pragma unroll
+                for (int m = 0; m < RW; ++m)
+#pragma unroll
+                    for (int nt = 0; nt < CW; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[nt], x0[m], acc[m][nt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);   // keep the refill behind the MFMAs that read the old fragments (same registers)
+                if (!(ABL & 2)) {
+#pragma unroll
+                    for (int nt = 0; nt < CW; ++nt) w1[nt] = wf[(1 * NT + nt) * 64];
+                    if (W0DB) {   // this K-step's w0 was requested a K-step ago; its successor goes out at once
+#pragma unroll
+                        for (int nt = 0; nt < CW; ++nt) w0[nt] = w0n[nt];
+#pragma unroll
+                        for (int nt = 0; nt < CW; ++nt) w0n[nt] = wf[(0 * NT + nt) * 64];
+                    }
+                }
+                // The halo requests follow the weight requests: the counter that orders vector-memory operations is in-order, so
+                // a weight fragment requested after an HBM load cannot be used before that load has landed.  Here the next such
+                // fragment is the w1 request of the NEXT K-step, used two K-steps from now.
+                if (!(ABL & 1) && FETCH) {
+                    if (ABL & 32) { if (ks == 0) h2_stage_load<KH, KW>(plan, nxt_grp, rl); }
+                    else h2_stage_load<KH, KW>(plan, nxt_grp, rl, ks * PER, (ks + 1) * PER);
+                }
+                // ... and the slice requested LAG K-steps ago goes to the partner LDS buffer, which nobody reads during this group
+                if (ROLL && more && !(ABL & 1) && ks >= LAG)
+                    h2_stage_store<KH, KW>(plan, lds + ((cb + 1) & 1) * G::BUF, rs, (ks - LAG) * PER, (ks - LAG + 1) * PER);
+                __builtin_amdgcn_sched_barrier(0);
+                // phase B1: x0*w0, then x0 is free for the next K-step's pixels
+#pragma unroll
+                for (int m = 0; m < RW; ++m)
+#pragma unroll
+                    for (int nt = 0; nt < CW; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[nt], x0[m], acc[m][nt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks + 1 < NK && !(ABL & 4)) {
+                    const char *pn = xaddr(ks + 1);
+#pragma unroll
+                    for (int m = 0; m < RW; ++m) x0[m] = *reinterpret_cast<const f16x8 *>(pn + m * G::TW * 32);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // phase B2: x1*w0, then w0 is free
+#pragma unroll
+                for (int m = 0; m < RW; ++m)
+#pragma unroll
+                    for (int nt = 0; nt < CW; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[nt], x1[m], acc[m][nt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!W0DB && !(ABL & 2)) {
+#pragma unroll
+                    for (int nt = 0; nt < CW; ++nt) w0[nt] = wf[(0 * NT + nt) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // the partner halo buffer is only overwritten here, after the last K-step that may read the previous group from it
+            if (MODE == 1 && g < 2) {   // deferred last tap of the even group, carried in registers across the barrier
                 const char *pl = buf + O_LAST + pb;
 #pragma unroll
                 for (int m = 0; m < RW; ++m) {
                     x0[m] = *reinterpret_cast<const f16x8 *>(pl + m * G::TW * 32);
                     x1[m] = *reinterpret_cast<const f16x8 *>(pl + G::PLANE * 16 + m * G::TW * 32);
                 }
-            }
-        } else {
-            const char *p0x = xaddr(0);
-#pragma unroll
-            for (int m = 0; m < RW; ++m) x0[m] = *reinterpret_cast<const f16x8 *>(p0x + m * G::TW * 32);
-        }
-#pragma unroll
-        for (int ks = 0; ks < NK; ++ks) {
-            asm volatile("" : "+v"(tapsel));   // keeps hipcc from hoisting every K-step's tap offset out of the group loop
-            const char *px = (MODE == 2 && ks == 0) ? buf : xaddr(ks);
-            ++stream;
-            if ((!(ABL & 4) || ks == 0) && !(MODE == 2 && ks == 0)) {
-#pragma unroll
-                for (int m = 0; m < RW; ++m) x1[m] = *reinterpret_cast<const f16x8 *>(px + G::PLANE * 16 + m * G::TW * 32);
-            }
-            // next K-step's fragments (L2-resident); the persistent kernel wraps around to the next tile's first K-step
-            const f16x8 *wf = wl + (size_t)(CHAIN ? (stream > last ? 0 : stream) : min(stream, last)) * (2 * NT * 64);
-            __builtin_amdgcn_sched_barrier(0);
-            // phase A: x0*w1, then w1 is free for the next K-step's fragments.  No vector-memory request precedes it inside
-            // the K-step: hipcc loses the exact outstanding-load count across the group loop's back edge and waits for
-            // vmcnt(0) at a group's first use of a weight fragment - which must not cover a halo request issued just before.
-#pragma unroll
-            for (int m = 0; m < RW; ++m)
-#pragma unroll
-                for (int nt = 0; nt < CW; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[nt], x0[m], acc[m][nt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);   // keep the refill behind the MFMAs that read the old fragments (same registers)
-            if (!(ABL & 2)) {
-#pragma unroll
-                for (int nt = 0; nt < CW; ++nt) w1[nt] = wf[(1 * NT + nt) * 64];
-                if (W0DB) {   // this K-step's w0 was requested a K-step ago; its successor goes out at once
-#pragma unroll
-                    for (int nt = 0; nt < CW; ++nt) w0[nt] = w0n[nt];
-#pragma unroll
-                    for (int nt = 0; nt < CW; ++nt) w0n[nt] = wf[(0 * NT + nt) * 64];
-                }
-            }
-            // The halo requests follow the weight requests: the counter that orders vector-memory operations is in-order, so
-            // a weight fragment requested after an HBM load cannot be used before that load has landed.  Here the next such
-            // fragment is the w1 request of the NEXT K-step, used two K-steps from now.
-            if (!(ABL & 1) && FETCH) {
-                if (ABL & 32) { if (ks == 0) h2_stage_load<KH, KW>(plan, nxt_grp, rl); }
-                else h2_stage_load<KH, KW>(plan, nxt_grp, rl, ks * PER, (ks + 1) * PER);
-            }
-            // ... and the slice requested LAG K-steps ago goes to the partner LDS buffer, which nobody reads during this group
-            if (ROLL && more && !(ABL & 1) && ks >= LAG)
-                h2_stage_store<KH, KW>(plan, lds + ((cb + 1) & 1) * G::BUF, rs, (ks - LAG) * PER, (ks - LAG + 1) * PER);
-            __builtin_amdgcn_sched_barrier(0);
-            // phase B1: x0*w0, then x0 is free for the next K-step's pixels
-#pragma unroll
-            for (int m = 0; m < RW; ++m)
-#pragma unroll
-                for (int nt = 0; nt < CW; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[nt], x0[m], acc[m][nt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (ks + 1 < NK && !(ABL & 4)) {
-                const char *pn = xaddr(ks + 1);
-#pragma unroll
-                for (int m = 0; m < RW; ++m) x0[m] = *reinterpret_cast<const f16x8 *>(pn + m * G::TW * 32);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // phase B2: x1*w0, then w0 is free
-#pragma unroll
-            for (int m = 0; m < RW; ++m)
-#pragma unroll
-                for (int nt = 0; nt < CW; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[nt], x1[m], acc[m][nt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (!W0DB && !(ABL & 2)) {
-#pragma unroll
-                for (int nt = 0; nt < CW; ++nt) w0[nt] = wf[(0 * NT + nt) * 64];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // the partner halo buffer is only overwritten here, after the last K-step that may read the previous group from it
-        if (MODE == 1 && g < 2) {   // deferred last tap of the even group, carried in registers across the barrier
-            const char *pl = buf + O_LAST + pb;
-#pragma unroll
-            for (int m = 0; m < RW; ++m) {
-                x0[m] = *reinterpret_cast<const f16x8 *>(pl + m * G::TW * 32);
-                x1[m] = *reinterpret_cast<const f16x8 *>(pl + G::PLANE * 16 + m * G::TW * 32);
             }
         }
         if (ABL & 128) { const unsigned long long t = h2_stamp(); t_k += t - tmark; tmark = t; }
@@ -304,8 +359,8 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
 template <int NT, int ABL>
 __device__ __forceinline__ void h2_epilogue(const ConvX6Args &a, f32x4 (&acc)[WaveTile<NT>::RW][WaveTile<NT>::CW], int n, int ty, int tx);
 
-template <int KH, int KW, int NT, bool SC, int ABL = 0>
-__global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv_h2_kernel(ConvX6Args a)
+template <int KH, int KW, int NT, bool SC, int ABL = 0, bool LEAN = false>
+__global__ __launch_bounds__(256, NT == 4 && !LEAN ? 2 : 3) void conv_h2_kernel(ConvX6Args a)
 {
     typedef GeoH<KH, KW> G;
     __shared__ u32x4 lds[2 * G::BUF];
@@ -328,7 +383,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv_h2_kernel(ConvX6Arg
     const unsigned long long t_begin = (ABL & 128) ? h2_stamp() : 0;
     {
         H2Carry<KH, KW, NT> carry;
-        h2_accumulate<KH, KW, NT, ABL>(a.x, a.x_stride, a.w, a.Cin, a.H, a.W, n, ty, tx, lds, acc,
+        h2_accumulate<KH, KW, NT, ABL, false, LEAN>(a.x, a.x_stride, a.w, a.Cin, a.H, a.W, n, ty, tx, lds, acc,
                                        a.dbg ? a.dbg + (size_t)blockIdx.x * 8 : nullptr, carry, true, n, ty, tx);
     }
     const unsigned long long t_acc = (ABL & 128) ? h2_stamp() : 0;
@@ -501,6 +556,9 @@ static hipError_t launch_h2(hipStream_t s, const ConvX6Args &a)
             case 128: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 128>), dim3(grid), dim3(256), 0, s, a); break;
             default: PMP_H2_LAUNCH(4); break;
             }
+        } else if (KH == 3 && !a.x_sc && !((a.Cin >> 4) & 1) && g_conv_variant == 5) {
+            // opt-in (PMP_CONV_VARIANT=5): 168 VGPRs, three workgroups per CU; measured 2 % slower
+            hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 0, true>), dim3(grid), dim3(256), 0, s, a);
         } else if (KH > 1 && !a.x_sc && !((a.Cin >> 4) & 1) && !(grid & 7) && g_conv_variant == 4) {
             // persistent form (opt-in, PMP_CONV_VARIANT=4): 2 workgroups per CU, 64 per XCD.  Measured 2 % SLOWER than one
             // workgroup per tile on the 1024-block luma step: kept as a tested A/B variant, not the default.

@@ -124,16 +124,17 @@ def test_f16x3_saturates_instead_of_overflowing(g1):
         e2.close()
 
 
-def test_f16x3_conv_variants_agree(g1):
-    """The opt-in persistent form of the f16x3 convolution (PMP_CONV_VARIANT=4, conv_f16x3.hip) must give the logits of
-    the default one-workgroup-per-tile form bit for bit: same K order, same accumulators."""
+@pytest.mark.parametrize("variant", [4, 5])
+def test_f16x3_conv_variants_agree(g1, variant):
+    """The opt-in forms of the f16x3 convolution (PMP_CONV_VARIANT=4 persistent, 5 three workgroups per CU; conv_f16x3.hip)
+    must give the logits of the default form bit for bit: same K order, same accumulators."""
     from pmp_vvc_tip2023_amd import engine
     e2 = engine.Engine(0)
     try:
         e2.set_precision("f16x3")
         y = np.concatenate([g1["block_y"]] * 8)              # 128 blocks: several tiles per persistent workgroup at 64x64
         ref = e2.inference_pre_QBD("Luma", 22, y)
-        assert e2.lib.pmp_debug_set_conv_variant(4) == 0
+        assert e2.lib.pmp_debug_set_conv_variant(variant) == 0
         try:
             got = e2.inference_pre_QBD("Luma", 22, y)
         finally:
