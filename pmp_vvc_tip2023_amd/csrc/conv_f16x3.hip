@@ -94,7 +94,7 @@ __device__ __forceinline__ void h2_stage_store(const StagePlanH<KH, KW> &p, u32x
 // around to the first K-step at the end of a tile - and the staging plan of the tile whose first halo group is in LDS.
 template <int KH, int KW, int NT>
 struct H2Carry {
-    f16x8 w0[WaveTile<NT>::CW], w1[WaveTile<NT>::CW], w0n[WaveTile<NT>::CW];
+    f16x8 w0[WaveTile<NT>::CW], w1[WaveTile<NT>::CW], w0n[WaveTile<NT>::CW], w1n[WaveTile<NT>::CW], w0nn[WaveTile<NT>::CW];
     StagePlanH<KH, KW> plan;
 };
 
@@ -122,6 +122,7 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
     // W0DB: a K-step's w0 fragments are requested one K-step ahead into a second register set and moved over between its
     // phases A and B1 (8 v_mov) - a full K-step of lead for the split that is used last and needed first.
     constexpr bool W0DB = NT == 4;
+    constexpr bool W2 = W0DB && G::TAPS == 9 && !CHAIN && !LEAN && !(ABL & 256);   // ABL 256: A/B build with one K-step of lead
     constexpr bool DEEP = G::TAPS <= 9 && NT == 4 && !W0DB;
     u32x4 r[G::NLD], rb[DEEP ? G::NLD : 1];
     StagePlanH<KH, KW> &plan = c.plan;
@@ -132,12 +133,20 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
     const int last = paired ? (CB / 2) * G::TAPS - 1 : CB * G::NKS - 1;   // last K-step of the weight stream
     f16x8 (&w0)[CW] = c.w0, (&w1)[CW] = c.w1;   // ONE weight set, refilled in place as soon as the last MFMA that reads a split has issued
     f16x8 (&w0n)[CW] = c.w0n;                  // W0DB: the K-step's w0 fragments land here and move to w0 between its phases A and B1
+    // W2: weight fragments are requested TWO K-steps ahead (16 more registers).  The L1 returns data in order for the whole
+    // CU, so a weight hit queued behind a halo request that went to HBM - this workgroup's or its neighbour's - waits for
+    // it; one K-step of lead (0.8-1.5 k cycles) is less than that round trip, two are more.
+    f16x8 (&w1n)[CW] = c.w1n, (&w0nn)[CW] = c.w0nn;
     if (!CHAIN || first) {   // a chained tile finds its weights in the carry and its first halo group in LDS buffer 0
         h2_plan<KH, KW>(plan, plane_stride, H, W, ty, tx);
 #pragma unroll
         for (int nt = 0; nt < CW; ++nt) {
             if (W0DB) w0n[nt] = wl[(0 * NT + nt) * 64]; else w0[nt] = wl[(0 * NT + nt) * 64];
             w1[nt] = wl[(1 * NT + nt) * 64];
+            if (W2) {
+                const f16x8 *w2 = wl + (size_t)min(1, last) * (2 * NT * 64);
+                w0nn[nt] = w2[(0 * NT + nt) * 64]; w1n[nt] = w2[(1 * NT + nt) * 64];
+            }
         }
         __syncthreads();
         h2_stage_load<KH, KW>(plan, grp0, r);
@@ -272,7 +281,15 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
 #pragma unroll
                     for (int nt = 0; nt < CW; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[nt], x0[m], acc[m][nt], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);   // keep the refill behind the MFMAs that read the old fragments (same registers)
-                if (!(ABL & 2)) {
+                if (W2 && !(ABL & 2)) {   // everything moves up one place, the fragments of K-step k+2 are requested
+                    const f16x8 *wf2 = wl + (size_t)min(stream + 1, last) * (2 * NT * 64);
+#pragma unroll
+                    for (int nt = 0; nt < CW; ++nt) { w1[nt] = w1n[nt]; w0[nt] = w0n[nt]; w0n[nt] = w0nn[nt]; }
+#pragma unroll
+                    for (int nt = 0; nt < CW; ++nt) w1n[nt] = wf2[(1 * NT + nt) * 64];
+#pragma unroll
+                    for (int nt = 0; nt < CW; ++nt) w0nn[nt] = wf2[(0 * NT + nt) * 64];
+                } else if (!(ABL & 2)) {
 #pragma unroll
                     for (int nt = 0; nt < CW; ++nt) w1[nt] = wf[(1 * NT + nt) * 64];
                     if (W0DB) {   // this K-step's w0 was requested a K-step ago; its successor goes out at once
@@ -384,7 +401,7 @@ __global__ __launch_bounds__(256, NT == 4 && !LEAN ? 2 : 3) void conv_h2_kernel(
     {
         H2Carry<KH, KW, NT> carry;
         h2_accumulate<KH, KW, NT, ABL, false, LEAN>(a.x, a.x_stride, a.w, a.Cin, a.H, a.W, n, ty, tx, lds, acc,
-                                       a.dbg ? a.dbg + (size_t)blockIdx.x * 8 : nullptr, carry, true, n, ty, tx);
+                                       a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr, carry, true, n, ty, tx);
     }
     const unsigned long long t_acc = (ABL & 128) ? h2_stamp() : 0;
     if (SC) {
@@ -395,8 +412,11 @@ __global__ __launch_bounds__(256, NT == 4 && !LEAN ? 2 : 3) void conv_h2_kernel(
     if ((ABL & 128) && a.dbg && threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // include the store acknowledgements in the epilogue span
         const unsigned long long t_end = h2_stamp();
-        unsigned long long *d = a.dbg + (size_t)blockIdx.x * 8;
+        unsigned long long *d = a.dbg + (size_t)blockIdx.x * 16;
         d[4] = t_acc - t_begin; d[5] = t_end - t_acc; d[6] = t_begin; d[7] = t_end;
+        unsigned hw, xcc;   // where the workgroup ran: HW_ID (cu/sh/se in bits 8..15) and XCC_ID
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+        d[8] = hw; d[9] = xcc;
     }
 }
 
@@ -554,6 +574,11 @@ static hipError_t launch_h2(hipStream_t s, const ConvX6Args &a)
             case 32: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 32>), dim3(grid), dim3(256), 0, s, a); break;
             case 64: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 64>), dim3(grid), dim3(256), 0, s, a); break;
             case 128: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 128>), dim3(grid), dim3(256), 0, s, a); break;
+            case 256: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 256>), dim3(grid), dim3(256), 0, s, a); break;
+            case 129: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 129>), dim3(grid), dim3(256), 0, s, a); break;
+            case 130: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 130>), dim3(grid), dim3(256), 0, s, a); break;
+            case 131: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 131>), dim3(grid), dim3(256), 0, s, a); break;
+            case 135: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 135>), dim3(grid), dim3(256), 0, s, a); break;
             default: PMP_H2_LAUNCH(4); break;
             }
         } else if (KH == 3 && !a.x_sc && !((a.Cin >> 4) & 1) && g_conv_variant == 5) {

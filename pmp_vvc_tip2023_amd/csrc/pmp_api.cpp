@@ -503,7 +503,7 @@ int pmp_write_partition_file(const char *path, int frames, int H, int W, const u
 
 int pmp_debug_set_conv_variant(int variant)
 {
-    if (variant < 0 || variant > 255) return set_err(nullptr, PMP_E_INVALID, "pmp_debug_set_conv_variant: 0..2 (10+bits: timing-only bf16x6 ablations)");
+    if (variant < 0 || variant > 1023) return set_err(nullptr, PMP_E_INVALID, "pmp_debug_set_conv_variant: 0..5, or 10 + bits for the timing-only builds");
     g_conv_variant = variant;
     return PMP_OK;
 }
@@ -594,26 +594,29 @@ int pmp_debug_conv_bench(pmp_ctx *c, int n, int h, int w, int cin, int cout, int
                 hipFree(ddbg);
             }
         }
-        if (h2 && g_conv_variant == 10 + 128 && k == 3 && cout == 64) {   // in-kernel stamp report (diagnostic build)
+        if (h2 && g_conv_variant >= 10 + 128 && g_conv_variant < 10 + 144 && k == 3 && cout == 64) {   // 128 + ablation bits 1/2/4   // in-kernel stamp report (diagnostic build)
             const int wgs = n * (h / 16) * (w / 16);
             unsigned long long *ddbg = nullptr;
-            if (hipMalloc((void **)&ddbg, (size_t)wgs * 8 * 8) == hipSuccess) {
-                hipMemset(ddbg, 0, (size_t)wgs * 8 * 8);
+            if (hipMalloc((void **)&ddbg, (size_t)wgs * 16 * 8) == hipSuccess) {
+                hipMemset(ddbg, 0, (size_t)wgs * 16 * 8);
                 b.dbg = ddbg;
                 launch_split();
                 hipStreamSynchronize(c->stream);
-                std::vector<unsigned long long> hd((size_t)wgs * 8);
+                std::vector<unsigned long long> hd((size_t)wgs * 16);
                 hipMemcpy(hd.data(), ddbg, hd.size() * 8, hipMemcpyDeviceToHost);
                 double s[6] = {0, 0, 0, 0, 0, 0};
                 unsigned long long tmin = ~0ull, tmax = 0;
                 for (int i = 0; i < wgs; ++i) {
-                    for (int j = 0; j < 6; ++j) s[j] += (double)hd[(size_t)i * 8 + j];
-                    tmin = std::min(tmin, hd[(size_t)i * 8 + 6]);
-                    tmax = std::max(tmax, hd[(size_t)i * 8 + 7]);
+                    for (int j = 0; j < 6; ++j) s[j] += (double)hd[(size_t)i * 16 + j];
+                    tmin = std::min(tmin, hd[(size_t)i * 16 + 6]);
+                    tmax = std::max(tmax, hd[(size_t)i * 16 + 7]);
                 }
                 fprintf(stderr, "f16x3 stamps (mean ticks per workgroup, wave 0): prologue %.0f | K-steps %.0f | halo LDS store incl. its wait %.0f | "
                                 "group barrier %.0f | accumulate total %.0f | epilogue incl. store ack %.0f | kernel span %.0f ticks, %d workgroups\n",
                         s[0] / wgs, s[1] / wgs, s[2] / wgs, s[3] / wgs, s[4] / wgs, s[5] / wgs, (double)(tmax - tmin), wgs);
+                if (const char *dump = getenv("PMP_STAMP_DUMP")) {   // raw stamps, 16 x u64 per workgroup (tools/stamp_overlap.py)
+                    if (FILE *f = fopen(dump, "wb")) { fwrite(hd.data(), 8, hd.size(), f); fclose(f); }
+                }
                 b.dbg = nullptr;
                 hipFree(ddbg);
             }

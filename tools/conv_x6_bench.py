@@ -16,9 +16,14 @@ if len(sys.argv) > 1 and sys.argv[1] == "ablate":
 if len(sys.argv) > 1 and sys.argv[1] == "ablate5":
     shapes = [(256, 64, 64, 64, 64, 5), (256, 64, 64, 32, 64, 5)]
     abl = [0, 32, 0, 32, 1, 2, 4, 8, 9, 15]
+elif len(sys.argv) > 1 and sys.argv[1] == "ab":   # same-box A/B of real (not ablated) builds: ab <bits> [shape]
+    bits = int(sys.argv[2]); abl = [0, bits] * 4
+    shapes = [tuple(int(v) for v in sys.argv[3].split(","))] if len(sys.argv) > 3 else [(1024, 64, 64, 64, 64, 3)]
+elif len(sys.argv) > 1 and sys.argv[1] == "stamps":   # only the stamp build (with PMP_STAMP_DUMP: raw stamps for tools/stamp_overlap.py)
+    shapes = [(256, 64, 64, 64, 64, 3)]; abl = [128 + (int(sys.argv[2]) if len(sys.argv) > 2 else 0)]   # + 1 no halo staging, 2 no weight refills, 4 no fragment reads (builds 0, 1, 2, 3, 7)
 elif len(sys.argv) > 1 and sys.argv[1] == "ablate_h2":
     abl = [0, 32, 64, 1, 2, 4, 8, 16, 9, 15, 128]   # 128: in-kernel stamps   # 64: all blocks read and write block 0's addresses (L2-resident working set: what HBM costs); 16: epilogue without its stores (and a quarter of the conversions); 32: all halo requests with the first K-step (a real variant, not an ablation)
-elif len(sys.argv) > 1 and sys.argv[1] not in ("ablate", "ablate5"):
+elif len(sys.argv) > 1 and sys.argv[1] not in ("ablate", "ablate5", "stamps", "ab"):
     shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
 for ab in abl:
   eng.lib.pmp_debug_set_conv_variant(10 + ab if ab else 2)
