@@ -3,10 +3,11 @@
 
 One "step" = one pass of the device-resident hot path (QT-net + MTT-net inference + Map2Partition
 post-processing, pmp_infer_postprocess_device) over one batch of synthetic blocks already resident in HBM.
-Workload at every N: BASELINE.json configs[1] — Luma QT+MTT nets, QP22, batch = 1024 synthetic blocks per GPU
+Workload at every N: BASELINE.json configs[1] — Luma QT+MTT nets, QP22, batch = 1024 synthetic 128x128 CTUs per GPU
 (recipe R; QT weights real, MTT weights synthetic because the reference's *_BD_*.pkl are missing).
-Unit: the nets consume 64x64 blocks (+4 px context); one VTM CTU is 128x128 = 4 blocks, so
-CTU/s = blocks/s / 4.  `value` is CTU/s; blocks/s is reported next to it.
+Unit: the nets consume 64x64 blocks (+4 px context); one VTM CTU is 128x128 = 4 blocks, so a step is 4096 blocks
+(the library walks them in chunks of 1024) and CTU/s = blocks/s / 4 (BASELINE.md section 2).  `value` is CTU/s;
+blocks/s is reported next to it.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]        (N>1: launched by torch.distributed.run)
 
@@ -104,7 +105,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1024, help="blocks per GPU per step")
+    ap.add_argument("--ctus", type=int, default=1024, help="128x128 CTUs per GPU per step (4 blocks each)")
+    ap.add_argument("--batch", type=int, default=0, help="blocks per GPU per step (overrides --ctus; tests and tools)")
     ap.add_argument("--comp", default="Luma", choices=["Luma", "Chroma"])
     ap.add_argument("--qp", type=int, default=22)
     ap.add_argument("--chunk", type=int, default=0, help="blocks per pass inside the library (0 = library default)")
@@ -153,7 +155,7 @@ def main():
     eng.load(args.comp, args.qp)
     log("rank %d: weights %s" % (rank, {k[0]: v for k, v in eng.provenance.items()}))
 
-    n = args.batch
+    n = args.batch if args.batch > 0 else 4 * args.ctus
     y, u, v = synth.recipe_r_blocks(n, 1 + rank)            # seed 1 on rank 0
     d_y = torch.from_numpy(y).to(dev)
     d_u = torch.from_numpy(u).to(dev)
@@ -224,10 +226,11 @@ def main():
             step()
         torch.cuda.synchronize(dev)
         tot = 0.0
+        per = 1024.0 / n / 3                                   # reported per 1024 blocks (one library chunk), as in DESIGN.md
         for k, (ln, kms, fl) in eng.ktime().items():
             tot += kms
-            log("  %-20s launches %5d  %9.3f ms/step  %7.2f TFLOP/s" % (k, ln // 3, kms / 3, (fl / (kms * 1e-3) / 1e12) if kms else 0))
-        log("  sum of kernel time %.3f ms/step" % (tot / 3))
+            log("  %-20s launches %6.2f  %9.3f ms per 1024 blocks  %7.2f TFLOP/s" % (k, ln * per, kms * per, (fl / (kms * 1e-3) / 1e12) if kms else 0))
+        log("  sum of kernel time %.3f ms per 1024 blocks (step = %d blocks)" % (tot * per, n))
         eng.ktime_enable(0)
 
     if rank == 0:
@@ -236,8 +239,8 @@ def main():
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else args.precision, "data": "synthetic",
-            "config": {"workload": "%s QT+MTT nets QP%d, batch=%d synthetic 64x64 blocks (68x68 u8 inputs) per GPU, "
-                                   "device-resident infer+Map2Partition; CTU = 128x128 = 4 blocks" % (args.comp, args.qp, n),
+            "config": {"workload": "%s QT+MTT nets QP%d, batch=%g synthetic 128x128 CTUs = %d 64x64 blocks (68x68 u8 inputs) per GPU, "
+                                   "device-resident infer+Map2Partition" % (args.comp, args.qp, n / 4.0, n),
                        "blocks_per_gpu": n, "global_blocks": n * n_gpus, "parallelism": "dp%d (blocks sharded, gather of split flags to rank 0)" % n_gpus,
                        "weights": "QT real (reference trained_models), MTT synthetic seed=qp",
                        "datapath": {"fp32": "fp32 MFMA",
