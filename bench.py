@@ -6,7 +6,7 @@ post-processing, pmp_infer_postprocess_device) over one batch of synthetic block
 Workload at every N: BASELINE.json configs[1] — Luma QT+MTT nets, QP22, batch = 1024 synthetic 128x128 CTUs per GPU
 (recipe R; QT weights real, MTT weights synthetic because the reference's *_BD_*.pkl are missing).
 Unit: the nets consume 64x64 blocks (+4 px context); one VTM CTU is 128x128 = 4 blocks, so a step is 4096 blocks
-(the library walks them in chunks of 1024) and CTU/s = blocks/s / 4 (BASELINE.md section 2).  `value` is CTU/s;
+(one library pass: the default chunk is 4096 blocks) and CTU/s = blocks/s / 4 (BASELINE.md section 2).  `value` is CTU/s;
 blocks/s is reported next to it.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]        (N>1: launched by torch.distributed.run)
@@ -210,8 +210,12 @@ def main():
         traffic = None
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.isfile(tp):
-            try:
-                traffic = json.load(open(tp)).get(DOMINANT + ":" + args.precision)
+            try:   # bytes per launch from the PMC passes, scaled to the blocks one launch processes here
+                tj = json.load(open(tp))
+                traffic = tj.get(DOMINANT + ":" + args.precision)
+                if traffic is not None:
+                    per_launch = min(n, args.chunk if args.chunk else 4096)
+                    traffic = round(traffic * per_launch / float(tj.get("_blocks_per_launch:" + args.precision, per_launch)))
             except Exception:
                 traffic = None
         peak = PEAK_TFLOPS[args.precision]

@@ -69,7 +69,8 @@ int pmp_destroy(pmp_ctx *ctx);
 int pmp_set_stream(pmp_ctx *ctx, void *hip_stream);
 int pmp_synchronize(pmp_ctx *ctx);
 
-/* Blocks processed per pass (activation workspace is sized for it); n > chunk is looped.  1..4096, default 1024. */
+/* Blocks processed per pass (activation workspace is sized for it); n > chunk is looped.  1..4096, default 4096
+ * (about 60 GB of workspace for a full luma chunk; the workspace only grows to what the largest pass so far needed). */
 int pmp_set_chunk(pmp_ctx *ctx, int blocks);
 
 /* Convolution datapath.  All three are fp32-accurate; results differ in the last bits only.

@@ -60,7 +60,7 @@ struct KTimeRec { hipEvent_t a, b; double flops; };
 struct pmp_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    int chunk = 1024;
+    int chunk = 4096;   // blocks per pass: the 16x16-resolution layers need >= 4096 tiles to fill 256 CUs x 3 workgroups evenly (+2.5 % over 1024)
     int precision = 2;                     // 0: fp32 MFMA, 1: bf16x6 split, 2: f16x3 split (default; both splits fp32-equivalent)
     std::string err;
     std::map<int, pmp::NetWeights> nets;  // key = net_id * 100 + qp

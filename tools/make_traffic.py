@@ -13,6 +13,7 @@ for k, v in src.items():
                                                                       ("f16x3" if k.startswith("conv_h2_kernel<3, 3, 4, sc=false") else None))
     if mode and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         out["conv_mfma_3x3_c64:" + mode] = round((2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0)
+        out["_blocks_per_launch:" + mode] = int(sys.argv[2]) if len(sys.argv) > 2 else 4096   # blocks per launch of the profiled run (bench.py scales)
         out["_detail:" + mode] = {"kernel": k, "FETCH_SIZE_KB": v["FETCH_SIZE"], "WRITE_SIZE_KB": v["WRITE_SIZE"],
                           "note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024, averaged over the launches of the kernel"}
 json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
