@@ -17,7 +17,7 @@ the reference hard-codes them:
   sequence file stem: the reference's rstrip(".yuv") strips a character SET (:166); a real suffix strip is used
   (identical for every name in VVC_Test_Sequences.txt and what EncAppCfg.cpp:4235-4242 expects).
   Nets are loaded once per (component, QP) instead of once per sequence (:208-224).
-  --batchSize is a lower bound on the blocks per pass (at least 1024 are used unless --strictBatch; identical results).
+  --batchSize is the reference's blocks-per-pass knob; passes of 4096 blocks are used unless --strictBatch (identical results).
   Frames are uploaded once per sequence and cut on the GPU; the blocks stay device-resident for all passes (--hostBlocks
   restores the reference's host-side block arrays).
 """
@@ -111,7 +111,7 @@ def build_parser():
     p.add_argument("--device", default=None, type=int, help="GPU index (default: LOCAL_RANK)")
     p.add_argument("--binary", action="store_true", help="also write <name>_PartitionMat.pmpb (binary side channel, include/pmp.h)")
     p.add_argument("--strictBatch", action="store_true",
-                   help="run exactly --batchSize blocks per pass (default: at least 1024, the library's chunk; same results)")
+                   help="run exactly --batchSize blocks per pass (default: the library's 4096-block chunk; same results)")
     p.add_argument("--hostBlocks", action="store_true",
                    help="keep the cut blocks in host memory and upload them for every (component, QP) pass, as the reference "
                         "does; default: frames are uploaded once, cut on the GPU and the blocks stay device-resident")
@@ -176,8 +176,8 @@ def inference_VVC_seqs(args):
         dev_id = local % max(torch.cuda.device_count(), 1)   # several ranks may share a GPU in smoke tests (gloo)
     eng = E.Engine(dev_id, weight_dir=args.modelDir if os.path.isdir(args.modelDir) else None)
     # --batchSize is the reference's blocks-per-forward-pass (a GPU memory knob there).  Results do not depend on it (tested:
-    # ragged chunks are bit-identical to one pass); small passes only leave most of an MI355X idle, so it is a lower bound here
-    eng.set_chunk(max(1, args.batchSize) if args.strictBatch else max(1024, min(4096, args.batchSize)))
+    # ragged chunks are bit-identical to one pass); small passes only leave most of an MI355X idle, so it is ignored unless --strictBatch asks for it
+    eng.set_chunk(max(1, args.batchSize) if args.strictBatch else 4096)
     device = None
     if world > 1:
         import torch
