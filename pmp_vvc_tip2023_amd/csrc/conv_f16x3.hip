@@ -190,10 +190,13 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
             return buf + (tapsel ? oB : oA) + pb;
         };
         if constexpr (LEAN) {
-            // 168-VGPR form for a third workgroup per CU: pixel fragments of 4 rows at a time, single-buffered (the other two
-            // waves of the SIMD cover the LDS round trip), and the cross-group tap read from the partner buffer instead of
-            // carried in 64 registers - with a barrier before that buffer's first rolling store.
+            // 168-VGPR form for a third workgroup per CU: pixel fragments of RS rows at a time, single-buffered (the other two
+            // waves of the SIMD cover the LDS round trip), both weight splits double-buffered one K-step ahead, and the
+            // cross-group tap read from the partner buffer instead of carried in 64 registers - with a barrier before that
+            // buffer's first rolling store.
+            constexpr int SUB = 4, RS = RW / SUB;   // 2-row sub-steps: 4-row ones spill (-15 %), 1-row ones expose more LDS round trips (-1 %)
             const char *part = reinterpret_cast<const char *>(lds + ((cb + 1) & 1) * G::BUF);
+            if (NK == 0 && FETCH) h2_stage_load<KH, KW>(plan, nxt_grp, rl);   // 1x1 source, even group: only fetch the partner group
 #pragma unroll
             for (int ks = 0; ks < NK; ++ks) {
                 asm volatile("" : "+v"(tapsel));
@@ -201,43 +204,43 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
                 ++stream;
                 const f16x8 *wf = wl + (size_t)(CHAIN ? (stream > last ? 0 : stream) : min(stream, last)) * (2 * NT * 64);
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    f16x8 xa[RW / 2], xb[RW / 2];
+                for (int h = 0; h < SUB; ++h) {
+                    f16x8 xa[RS], xb[RS];
 #pragma unroll
-                    for (int m = 0; m < RW / 2; ++m) {
-                        xa[m] = *reinterpret_cast<const f16x8 *>(px + (h * (RW / 2) + m) * G::TW * 32);
-                        xb[m] = *reinterpret_cast<const f16x8 *>(px + G::PLANE * 16 + (h * (RW / 2) + m) * G::TW * 32);
+                    for (int m = 0; m < RS; ++m) {
+                        xa[m] = *reinterpret_cast<const f16x8 *>(px + (h * RS + m) * G::TW * 32);
+                        xb[m] = *reinterpret_cast<const f16x8 *>(px + G::PLANE * 16 + (h * RS + m) * G::TW * 32);
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int m = 0; m < RW / 2; ++m)
+                    for (int m = 0; m < RS; ++m)
 #pragma unroll
                         for (int nt = 0; nt < CW; ++nt)
-                            acc[h * (RW / 2) + m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[nt], xa[m], acc[h * (RW / 2) + m][nt], 0, 0, 0);
+                            acc[h * RS + m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[nt], xa[m], acc[h * RS + m][nt], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (h == 0) {
 #pragma unroll
                         for (int nt = 0; nt < CW; ++nt) w0[nt] = w0n[nt];
 #pragma unroll
-                        for (int nt = 0; nt < CW; ++nt) w0n[nt] = wf[(0 * NT + nt) * 64];
+                        for (int nt = 0; nt < CW; ++nt) { w1n[nt] = wf[(1 * NT + nt) * 64]; w0n[nt] = wf[(0 * NT + nt) * 64]; }
                         if (FETCH) h2_stage_load<KH, KW>(plan, nxt_grp, rl, ks * PER, (ks + 1) * PER);
                         if (more && ks >= LAG)
                             h2_stage_store<KH, KW>(plan, lds + ((cb + 1) & 1) * G::BUF, rs, (ks - LAG) * PER, (ks - LAG + 1) * PER);
-                    } else {
+                    } else if (h == SUB - 1) {
 #pragma unroll
-                        for (int nt = 0; nt < CW; ++nt) w1[nt] = wf[(1 * NT + nt) * 64];
+                        for (int nt = 0; nt < CW; ++nt) w1[nt] = w1n[nt];
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int m = 0; m < RW / 2; ++m)
+                    for (int m = 0; m < RS; ++m)
 #pragma unroll
                         for (int nt = 0; nt < CW; ++nt)
-                            acc[h * (RW / 2) + m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[nt], xa[m], acc[h * (RW / 2) + m][nt], 0, 0, 0);
+                            acc[h * RS + m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[nt], xa[m], acc[h * RS + m][nt], 0, 0, 0);
 #pragma unroll
-                    for (int m = 0; m < RW / 2; ++m)
+                    for (int m = 0; m < RS; ++m)
 #pragma unroll
                         for (int nt = 0; nt < CW; ++nt)
-                            acc[h * (RW / 2) + m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[nt], xb[m], acc[h * (RW / 2) + m][nt], 0, 0, 0);
+                            acc[h * RS + m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[nt], xb[m], acc[h * RS + m][nt], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (MODE == 2 && ks == 0) h2_lds_barrier();   // every wave has read the partner buffer's last tap
@@ -406,7 +409,7 @@ __global__ __launch_bounds__(256, NT == 4 && !LEAN ? 2 : 3) void conv_h2_kernel(
     const unsigned long long t_acc = (ABL & 128) ? h2_stamp() : 0;
     if (SC) {
         H2Carry<1, 1, NT> carry;
-        h2_accumulate<1, 1, NT, 0>(a.x_sc, a.sc_stride, a.w_sc, a.Csc, a.H, a.W, n, ty, tx, lds, acc, nullptr, carry, true, n, ty, tx);
+        h2_accumulate<1, 1, NT, 0, false, LEAN>(a.x_sc, a.sc_stride, a.w_sc, a.Csc, a.H, a.W, n, ty, tx, lds, acc, nullptr, carry, true, n, ty, tx);
     }
     h2_epilogue<NT, ABL>(a, acc, n, ty, tx);
     if ((ABL & 128) && a.dbg && threadIdx.x == 0) {
@@ -581,12 +584,14 @@ static hipError_t launch_h2(hipStream_t s, const ConvX6Args &a)
             case 135: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 135>), dim3(grid), dim3(256), 0, s, a); break;
             default: PMP_H2_LAUNCH(4); break;
             }
-        } else if (KH == 3 && !a.x_sc && !((a.Cin >> 4) & 1) && g_conv_variant == 5) {
-            // opt-in (PMP_CONV_VARIANT=5): 168 VGPRs, three workgroups per CU; measured 2 % slower
-            hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 0, true>), dim3(grid), dim3(256), 0, s, a);
+        } else if (KH > 1 && !a.x_sc && g_conv_variant != 3 && g_conv_variant != 4) {
+            // default for the Cout = 64 layers without a shortcut source: the 168-VGPR form, three workgroups per CU
+            // (3x3: -5.6 %, 5x5: -1.9 % against the two-workgroup form, which PMP_CONV_VARIANT=3 selects for A/B timing; the
+            // shortcut instantiations would spill 70 registers in this form and stay as they are)
+            hipLaunchKernelGGL((conv_h2_kernel<KH, KW, 4, false, 0, true>), dim3(grid), dim3(256), 0, s, a);
         } else if (KH > 1 && !a.x_sc && !((a.Cin >> 4) & 1) && !(grid & 7) && g_conv_variant == 4) {
             // persistent form (opt-in, PMP_CONV_VARIANT=4): 2 workgroups per CU, 64 per XCD.  Measured 2 % SLOWER than one
-            // workgroup per tile on the 1024-block luma step: kept as a tested A/B variant, not the default.
+            // workgroup per tile in its two-workgroup form: kept as a tested A/B variant, not the default.
             hipLaunchKernelGGL((conv_h2_persist_kernel<KH, KW, 4>), dim3(8 * min(64, grid >> 3)), dim3(256), 0, s, a);
         } else {
             PMP_H2_LAUNCH(4);

@@ -15,9 +15,9 @@ def short(name):
     m = re.search(r"(conv_x6_kernel)<(\d+), ?(\d+), ?(\d+)", name)
     if m:
         return "conv_x6_kernel<%s, %s, %s>" % m.groups()[1:]
-    m = re.search(r"(conv_h2_kernel)<(\d+), ?(\d+), ?(\d+), ?(\w+)", name)
-    if m:
-        return "conv_h2_kernel<%s, %s, %s, sc=%s>" % m.groups()[1:]
+    m = re.search(r"(conv_h2_kernel)<(\d+), ?(\d+), ?(\d+), ?(\w+)(?:, ?(\d+), ?(\w+))?", name)
+    if m:   # the trailing flag of the template list: the 168-VGPR three-workgroups-per-CU form
+        return "conv_h2_kernel<%s, %s, %s, sc=%s>%s" % (m.group(2), m.group(3), m.group(4), m.group(5), " 3wg" if m.group(7) in ("true", "1") else "")
     name = name.replace("void ", "").replace("pmp::", "").replace("(anonymous namespace)::", "")
     return name[:70]
 
