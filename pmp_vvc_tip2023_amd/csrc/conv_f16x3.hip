@@ -153,6 +153,12 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
         if (DEEP && paired) h2_stage_load<KH, KW>(plan, grp0 + grp_sz, reinterpret_cast<u32x4 (&)[G::NLD]>(rb));   // group 1 exists: CB is even
         h2_stage_store<KH, KW>(plan, lds, r);
         __syncthreads();
+    } else if (LEAN) {
+        // 168 VGPRs cannot carry the plan and four weight sets across the epilogue: a chained tile of the three-workgroup
+        // form recomputes its plan and requests its first weights again (L2 hits); only the halo group in LDS is carried
+        h2_plan<KH, KW>(plan, plane_stride, H, W, ty, tx);
+#pragma unroll
+        for (int nt = 0; nt < CW; ++nt) { w0n[nt] = wl[(0 * NT + nt) * 64]; w1[nt] = wl[(1 * NT + nt) * 64]; }
     }
     if (ABL & 128) { const unsigned long long t = h2_stamp(); t_pro = t - tmark; tmark = t; }
     // ABL: timing-only builds (tools/conv_x6_bench.py h2 ablate): 1 no halo staging, 2 no weight refills, 4 no fragment reads, 8 no epilogue
@@ -433,8 +439,8 @@ __global__ __launch_bounds__(256, NT == 4 && !LEAN ? 2 : 3) void conv_h2_kernel(
 // group of the workgroup's next tile and the weight stream wraps around, so a tile starts at its first MFMA: no dispatch
 // gap, no prologue (halo round trip + barriers) between tiles.  It is NOT faster (the layer is bound by what the K-loop and
 // the epilogue move, not by the gaps), so launch_h2 only takes it on request.
-template <int KH, int KW, int NT, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void conv_h2_persist_kernel(ConvX6Args a)
+template <int KH, int KW, int NT, int ABL = 0, bool LEAN = false>
+__global__ __launch_bounds__(256, LEAN ? 3 : 2) void conv_h2_persist_kernel(ConvX6Args a)
 {
     typedef GeoH<KH, KW> G;
     __shared__ u32x4 lds[2 * G::BUF];
@@ -453,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_persist_kernel(ConvX6Args a)
         for (int m = 0; m < RW; ++m)
 #pragma unroll
             for (int nt = 0; nt < CW; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        h2_accumulate<KH, KW, NT, ABL, true>(a.x, a.x_stride, a.w, a.Cin, a.H, a.W, n, ty, tx, lds, acc, nullptr, carry, first, n2, ty2, tx2);
+        h2_accumulate<KH, KW, NT, ABL, true, LEAN>(a.x, a.x_stride, a.w, a.Cin, a.H, a.W, n, ty, tx, lds, acc, nullptr, carry, first, n2, ty2, tx2);
         first = false;
         h2_epilogue<NT, ABL>(a, acc, n, ty, tx);
     }
@@ -464,7 +470,9 @@ __device__ __forceinline__ void h2_epilogue(const ConvX6Args &a, f32x4 (&acc)[Wa
 {
     typedef WaveTile<NT> WT;
     constexpr int RW = WT::RW, CW = WT::CW;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, xl = lane & 15, g = lane >> 4;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));   // opaque: in the persistent kernels nothing lane-dependent of the epilogue is hoisted out of the tile loop
+    const int lane = tid & 63, wave = tid >> 6, xl = lane & 15, g = lane >> 4;
     const int rh = wave % WT::RSPLIT, ch = wave / WT::RSPLIT;
     const int H = a.H, W = a.W;
     const size_t grp = (size_t)H * W * 16;
@@ -583,13 +591,14 @@ static hipError_t launch_h2(hipStream_t s, const ConvX6Args &a)
             case 64: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 64>), dim3(grid), dim3(256), 0, s, a); break;
             case 128: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 128>), dim3(grid), dim3(256), 0, s, a); break;
             case 256: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 256>), dim3(grid), dim3(256), 0, s, a); break;
+            case 1152: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 128, true>), dim3(grid), dim3(256), 0, s, a); break;   // stamps of the default (three-workgroup) form
             case 129: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 129>), dim3(grid), dim3(256), 0, s, a); break;
             case 130: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 130>), dim3(grid), dim3(256), 0, s, a); break;
             case 131: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 131>), dim3(grid), dim3(256), 0, s, a); break;
             case 135: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 135>), dim3(grid), dim3(256), 0, s, a); break;
             default: PMP_H2_LAUNCH(4); break;
             }
-        } else if (KH > 1 && !a.x_sc && g_conv_variant != 3 && g_conv_variant != 4) {
+        } else if (KH > 1 && !a.x_sc && g_conv_variant != 3 && g_conv_variant != 4 && g_conv_variant != 5) {
             // default for the Cout = 64 layers without a shortcut source: the 168-VGPR form, three workgroups per CU
             // (3x3: -5.6 %, 5x5: -1.9 % against the two-workgroup form, which PMP_CONV_VARIANT=3 selects for A/B timing; the
             // shortcut instantiations would spill 70 registers in this form and stay as they are)
@@ -598,6 +607,10 @@ static hipError_t launch_h2(hipStream_t s, const ConvX6Args &a)
             // persistent form (opt-in, PMP_CONV_VARIANT=4): 2 workgroups per CU, 64 per XCD.  Measured 2 % SLOWER than one
             // workgroup per tile in its two-workgroup form: kept as a tested A/B variant, not the default.
             hipLaunchKernelGGL((conv_h2_persist_kernel<KH, KW, 4>), dim3(8 * min(64, grid >> 3)), dim3(256), 0, s, a);
+        } else if (KH == 3 && !a.x_sc && !((a.Cin >> 4) & 1) && !(grid & 7) && g_conv_variant == 5) {
+            // persistent three-workgroup form (opt-in, PMP_CONV_VARIANT=5): 96 workgroups per XCD.  The tile loop costs about 50
+            // more VGPRs than 168 leave (216 B of scratch, a third of it inside the K-loop): 17 % slower than the default.
+            hipLaunchKernelGGL((conv_h2_persist_kernel<3, 3, 4, 0, true>), dim3(8 * min(96, grid >> 3)), dim3(256), 0, s, a);
         } else {
             PMP_H2_LAUNCH(4);
         }

@@ -503,7 +503,7 @@ int pmp_write_partition_file(const char *path, int frames, int H, int W, const u
 
 int pmp_debug_set_conv_variant(int variant)
 {
-    if (variant < 0 || variant > 1023) return set_err(nullptr, PMP_E_INVALID, "pmp_debug_set_conv_variant: 0..5, or 10 + bits for the timing-only builds");
+    if (variant < 0 || variant > 4095) return set_err(nullptr, PMP_E_INVALID, "pmp_debug_set_conv_variant: 0..5, or 10 + bits for the timing-only builds");
     g_conv_variant = variant;
     return PMP_OK;
 }
@@ -594,7 +594,7 @@ int pmp_debug_conv_bench(pmp_ctx *c, int n, int h, int w, int cin, int cout, int
                 hipFree(ddbg);
             }
         }
-        if (h2 && g_conv_variant >= 10 + 128 && g_conv_variant < 10 + 144 && k == 3 && cout == 64) {   // 128 + ablation bits 1/2/4   // in-kernel stamp report (diagnostic build)
+        if (h2 && ((g_conv_variant >= 10 + 128 && g_conv_variant < 10 + 144) || g_conv_variant == 10 + 1152) && k == 3 && cout == 64) {   // 128 + ablation bits 1/2/4; 1152: the three-workgroup form   // in-kernel stamp report (diagnostic build)
             const int wgs = n * (h / 16) * (w / 16);
             unsigned long long *ddbg = nullptr;
             if (hipMalloc((void **)&ddbg, (size_t)wgs * 16 * 8) == hipSuccess) {

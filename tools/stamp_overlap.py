@@ -12,6 +12,10 @@ d = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 16)
 pro, acc, epi, beg, end = (d[:, i].astype(np.int64) for i in (0, 4, 5, 6, 7))
 hw, xcc = d[:, 8].astype(np.int64), d[:, 9].astype(np.int64)
 cu = (xcc & 0xF) * 256 + ((hw >> 8) & 0xFF)
+ok = (beg > 0) & (end > beg)
+if not ok.all():
+    print("dropping %d workgroups without stamps" % int((~ok).sum()))
+    pro, acc, epi, beg, end, hw, xcc, cu, d = pro[ok], acc[ok], epi[ok], beg[ok], end[ok], hw[ok], xcc[ok], cu[ok], d[ok]
 print("workgroups %d on %d CUs; life %.0f ticks (prologue %.0f, accumulate %.0f, epilogue %.0f)" % (
     len(d), len(np.unique(cu)), (end - beg).mean(), pro.mean(), acc.mean(), epi.mean()))
 res = np.zeros(4); kph = np.zeros(4); span_tot = 0.0; gaps = []; offs = []
@@ -22,10 +26,10 @@ for c in np.unique(cu):
     ev = []   # (time, d_resident, d_kphase)
     for i in idx:
         ev += [(beg[i], 1, 0), (beg[i] + pro[i], 0, 1), (beg[i] + acc[i], 0, -1), (end[i], -1, 0)]
-    ev.sort()
+    ev.sort(key=lambda e: (e[0], -e[1], -e[2]))   # at equal times arrivals before departures
     r = k = 0; last = t0
     for t, dr, dk in ev:
-        res[min(r, 3)] += t - last; kph[min(k, 3)] += t - last; last = t
+        res[max(0, min(r, 3))] += t - last; kph[max(0, min(k, 3))] += t - last; last = t
         r += dr; k += dk
     span_tot += t1 - t0
     # slot hand-over gap: a workgroup's begin minus the latest end before it (when both slots were taken)
