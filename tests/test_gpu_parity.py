@@ -220,14 +220,14 @@ def test_block_cutter_1080p_vs_oracle(eng, oracle_lib):
 
 # ------------------------------------------------------------------------------------------------ full path, full size
 def test_config2_full_batch_properties(eng, oracle_lib):
-    """BASELINE.json configs[1] size (1024 luma blocks, QP22), device-resident fused path:
+    """BASELINE.json configs[1] size (1024 luma CTUs = 4096 blocks, QP22: one bench.py step), device-resident fused path:
     * fused infer+postprocess == postprocess(infer) bit for bit, and is deterministic across runs
     * split flags are bit-exact against the oracle post-processing of the SAME device logits
     * logits of a 24-block sample within 1e-3 of the torch oracle
     * invariants of every valid partition (block borders are edges, QT map 2x2-constant, dire in {-1,0,1})."""
     from oracle import nets_torch as O
     from pmp_vvc_tip2023_amd import synth, weights as W
-    n = 1024
+    n = 4096
     y, u, v = synth.recipe_r_blocks(n, 1)
     eng.load("Luma", 22)
     dev = torch.device("cuda:0")
