@@ -71,8 +71,20 @@ def test_logits_vs_oracle_fresh_inputs_and_chunking(eng, comp):
     try:
         qt2, bt2, dire2 = eng.inference_pre_QBD(comp, qp, y, u, v)
     finally:
-        eng.set_chunk(1024)
+        eng.set_chunk(4096)
     assert np.array_equal(qt, qt2) and np.array_equal(bt, bt2) and np.array_equal(dire, dire2)
+
+
+def test_default_chunk_boundary(eng):
+    """More blocks than one library pass (default chunk 4096): the ragged second pass gives what a call on those blocks alone gives."""
+    from pmp_vvc_tip2023_amd import synth
+    y, _, _ = synth.recipe_r_blocks(16, 11)
+    big = np.concatenate([y] * 257)[:4100]                    # 4096 + 4
+    qt, bt, dire = eng.inference_pre_QBD("Luma", 22, big)
+    q2, b2, d2 = eng.inference_pre_QBD("Luma", 22, big[4096:])
+    assert np.array_equal(qt[4096:], q2) and np.array_equal(bt[4096:], b2) and np.array_equal(dire[4096:], d2)
+    q3, b3, d3 = eng.inference_pre_QBD("Luma", 22, big[:16])
+    assert np.array_equal(qt[:16], q3) and np.array_equal(bt[:16], b3) and np.array_equal(dire[:16], d3)
 
 
 def test_caller_supplied_weights_and_errors(eng, g1):
