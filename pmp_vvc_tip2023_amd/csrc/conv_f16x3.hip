@@ -490,6 +490,8 @@ __device__ __forceinline__ void h2_epilogue(const ConvX6Args &a, f32x4 (&acc)[Wa
         if (sacc == 123.456f) a.out[0] = 1;
         return;
     }
+    // (A straight-line special case for ReLU + split-2 output without gate/pool measured 2 % SLOWER than this general path
+    // with its wave-uniform branches per cout group: the branches keep one group's stores ahead of the next group's conversions.)
     // All residual (then gate) fragments are requested before the first store: the weight, pixel and staging registers are
     // dead by now, and a load issued after a store to `out` would otherwise have to wait for it (possible aliasing).
     if (a.res) {
