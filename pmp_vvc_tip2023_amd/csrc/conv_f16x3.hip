@@ -40,51 +40,51 @@ __device__ __forceinline__ unsigned long long h2_stamp()
     return t;
 }
 
-template <int KH, int KW>
+template <int KH, int KW, int NTHR = 256>
 struct StagePlanH {
-    unsigned off[GeoH<KH, KW>::NLD];
+    unsigned off[GeoH<KH, KW, 16, NTHR>::NLD];
     unsigned valid;
 };
 
-template <int KH, int KW>
-__device__ __forceinline__ void h2_plan(StagePlanH<KH, KW> &p, size_t plane_stride, int H, int W, int ty, int tx)
+template <int KH, int KW, int NTHR = 256>
+__device__ __forceinline__ void h2_plan(StagePlanH<KH, KW, NTHR> &p, size_t plane_stride, int H, int W, int ty, int tx)
 {
-    typedef GeoH<KH, KW> G;
+    typedef GeoH<KH, KW, 16, NTHR> G;
     constexpr int PY = KH / 2, PX = KW / 2;
     p.valid = 0;
 #pragma unroll
     for (int k = 0; k < G::NLD; ++k) {
-        const int i = min((int)threadIdx.x + k * 256, G::PIECES - 1);
+        const int i = min((int)threadIdx.x + k * NTHR, G::PIECES - 1);
         const int sp = i / G::PLANE, j = i - sp * G::PLANE, pix = j >> 1, half = j & 1;
         const int row = pix / G::TW, col = pix - row * G::TW;
         const int gy = ty * 16 + row - PY, gx = tx * 16 + col - PX;
-        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W && (int)threadIdx.x + k * 256 < G::PIECES;
+        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W && (int)threadIdx.x + k * NTHR < G::PIECES;
         if (in) p.valid |= 1u << k;
         const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);   // clamped: loads stay unconditional
         p.off[k] = (unsigned)(sp * plane_stride + ((size_t)cy * W + cx) * 16 + half * 8);
     }
 }
 
-template <int KH, int KW>
-__device__ __forceinline__ void h2_stage_load(const StagePlanH<KH, KW> &p, const unsigned short *__restrict__ grp,
-                                              u32x4 (&r)[GeoH<KH, KW>::NLD], int k0 = 0, int k1 = 1 << 20)
+template <int KH, int KW, int NTHR = 256>
+__device__ __forceinline__ void h2_stage_load(const StagePlanH<KH, KW, NTHR> &p, const unsigned short *__restrict__ grp,
+                                              u32x4 (&r)[GeoH<KH, KW, 16, NTHR>::NLD], int k0 = 0, int k1 = 1 << 20)
 {
 #pragma unroll
-    for (int k = 0; k < GeoH<KH, KW>::NLD; ++k) {
+    for (int k = 0; k < GeoH<KH, KW, 16, NTHR>::NLD; ++k) {
         if (k < k0 || k >= k1) continue;   // folds away: callers pass constants into unrolled code
         r[k] = *reinterpret_cast<const u32x4 *>(grp + p.off[k]);
     }
 }
 
-template <int KH, int KW>
-__device__ __forceinline__ void h2_stage_store(const StagePlanH<KH, KW> &p, u32x4 *lds, const u32x4 (&r)[GeoH<KH, KW>::NLD],
+template <int KH, int KW, int NTHR = 256>
+__device__ __forceinline__ void h2_stage_store(const StagePlanH<KH, KW, NTHR> &p, u32x4 *lds, const u32x4 (&r)[GeoH<KH, KW, 16, NTHR>::NLD],
                                                int k0 = 0, int k1 = 1 << 20)
 {
-    typedef GeoH<KH, KW> G;
+    typedef GeoH<KH, KW, 16, NTHR> G;
 #pragma unroll
     for (int k = 0; k < G::NLD; ++k) {
         if (k < k0 || k >= k1) continue;
-        const int i = min((int)threadIdx.x + k * 256, G::PIECES);   // pieces past the tile all land in one spare slot
+        const int i = min((int)threadIdx.x + k * NTHR, G::PIECES);   // pieces past the tile all land in one spare slot
         const u32x4 z = {0u, 0u, 0u, 0u};
         lds[i] = ((p.valid >> k) & 1u) ? r[k] : z;   // LDS image: [split][pixel][2 halves], linear
     }
@@ -92,22 +92,24 @@ __device__ __forceinline__ void h2_stage_store(const StagePlanH<KH, KW> &p, u32x
 
 // State that outlives one tile in the persistent kernel (CHAIN): the weight fragments of the next K-step - the stream wraps
 // around to the first K-step at the end of a tile - and the staging plan of the tile whose first halo group is in LDS.
-template <int KH, int KW, int NT>
+template <int KH, int KW, int NT, bool W8 = false>
 struct H2Carry {
-    f16x8 w0[WaveTile<NT>::CW], w1[WaveTile<NT>::CW], w0n[WaveTile<NT>::CW], w1n[WaveTile<NT>::CW], w0nn[WaveTile<NT>::CW];
-    StagePlanH<KH, KW> plan;
+    static constexpr int CW = WaveTile<NT, W8>::CW;
+    f16x8 w0[CW], w1[CW], w0n[CW], w1n[CW], w0nn[CW];
+    StagePlanH<KH, KW, W8 ? 512 : 256> plan;
 };
 
-template <int KH, int KW, int NT, int ABL = 0, bool CHAIN = false, bool LEAN = false>
+template <int KH, int KW, int NT, int ABL = 0, bool CHAIN = false, bool LEAN = false, bool W8 = false>
 __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__ x, size_t plane_stride,
                                               const unsigned short *__restrict__ wpk, int C, int H, int W, int n, int ty,
-                                              int tx, u32x4 *lds, f32x4 (&acc)[WaveTile<NT>::RW][WaveTile<NT>::CW],
-                                              unsigned long long *dbg, H2Carry<KH, KW, NT> &c, bool first, int n2, int ty2, int tx2)
+                                              int tx, u32x4 *lds, f32x4 (&acc)[WaveTile<NT, W8>::RW][WaveTile<NT, W8>::CW],
+                                              unsigned long long *dbg, H2Carry<KH, KW, NT, W8> &c, bool first, int n2, int ty2, int tx2)
 {
+    constexpr int NTHR = W8 ? 512 : 256;
     unsigned long long t_pro = 0, t_k = 0, t_s = 0, t_b = 0, tmark = 0;   // diagnostic accumulators (ABL & 128)
     if (ABL & 128) tmark = h2_stamp();
-    typedef GeoH<KH, KW> G;
-    typedef WaveTile<NT> WT;
+    typedef GeoH<KH, KW, 16, NTHR> G;
+    typedef WaveTile<NT, W8> WT;
     constexpr int RW = WT::RW, CW = WT::CW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, xl = lane & 15, g = lane >> 4;
     const int rh = wave % WT::RSPLIT, ch = wave / WT::RSPLIT;   // this wave: rows RW*rh.., cout groups CW*ch..
@@ -125,7 +127,7 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
     constexpr bool W2 = W0DB && G::TAPS == 9 && !CHAIN && !LEAN && !(ABL & 256);   // ABL 256: A/B build with one K-step of lead
     constexpr bool DEEP = G::TAPS <= 9 && NT == 4 && !W0DB;
     u32x4 r[G::NLD], rb[DEEP ? G::NLD : 1];
-    StagePlanH<KH, KW> &plan = c.plan;
+    StagePlanH<KH, KW, NTHR> &plan = c.plan;
     // Tap pairing as in conv_bf16x6.hip: mode 0 plain (last pair zero-padded), mode 1 even group of a pair (its last tap
     // is deferred and carried in registers), mode 2 odd group (first K-step = the deferred tap + its own last tap).
     const bool paired = (CB & 1) == 0 && (G::TAPS & 1);
@@ -138,7 +140,7 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
     // it; one K-step of lead (0.8-1.5 k cycles) is less than that round trip, two are more.
     f16x8 (&w1n)[CW] = c.w1n, (&w0nn)[CW] = c.w0nn;
     if (!CHAIN || first) {   // a chained tile finds its weights in the carry and its first halo group in LDS buffer 0
-        h2_plan<KH, KW>(plan, plane_stride, H, W, ty, tx);
+        h2_plan<KH, KW, NTHR>(plan, plane_stride, H, W, ty, tx);
 #pragma unroll
         for (int nt = 0; nt < CW; ++nt) {
             if (W0DB) w0n[nt] = wl[(0 * NT + nt) * 64]; else w0[nt] = wl[(0 * NT + nt) * 64];
@@ -149,14 +151,14 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
             }
         }
         __syncthreads();
-        h2_stage_load<KH, KW>(plan, grp0, r);
-        if (DEEP && paired) h2_stage_load<KH, KW>(plan, grp0 + grp_sz, reinterpret_cast<u32x4 (&)[G::NLD]>(rb));   // group 1 exists: CB is even
-        h2_stage_store<KH, KW>(plan, lds, r);
+        h2_stage_load<KH, KW, NTHR>(plan, grp0, r);
+        if (DEEP && paired) h2_stage_load<KH, KW, NTHR>(plan, grp0 + grp_sz, reinterpret_cast<u32x4 (&)[G::NLD]>(rb));   // group 1 exists: CB is even
+        h2_stage_store<KH, KW, NTHR>(plan, lds, r);
         __syncthreads();
     } else if (LEAN) {
         // 168 VGPRs cannot carry the plan and four weight sets across the epilogue: a chained tile of the three-workgroup
         // form recomputes its plan and requests its first weights again (L2 hits); only the halo group in LDS is carried
-        h2_plan<KH, KW>(plan, plane_stride, H, W, ty, tx);
+        h2_plan<KH, KW, NTHR>(plan, plane_stride, H, W, ty, tx);
 #pragma unroll
         for (int nt = 0; nt < CW; ++nt) { w0n[nt] = wl[(0 * NT + nt) * 64]; w1[nt] = wl[(1 * NT + nt) * 64]; }
     }
@@ -184,7 +186,7 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
         u32x4 (&rs)[G::NLD] = (DIST == 2 && MODE == 1) ? rbb : r;   // written to LDS at the end of this group (for group cb+1)
         constexpr bool more = !LAST || CHAINF;
         // the plan's last use for this tile was the request of this group during the previous one
-        if (CHAINF) h2_plan<KH, KW>(plan, plane_stride, H, W, ty2, tx2);
+        if (CHAINF) h2_plan<KH, KW, NTHR>(plan, plane_stride, H, W, ty2, tx2);
         const unsigned short *nxt_grp = CHAINF ? x + (size_t)n2 * CB * grp_sz
                                                : grp0 + (size_t)min(cb + DIST, CB - 1) * grp_sz;   // clamped (odd group in a deep pair before the tail)
         const char *buf = reinterpret_cast<const char *>(lds + (cb & 1) * G::BUF);
@@ -200,9 +202,9 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
             // waves of the SIMD cover the LDS round trip), both weight splits double-buffered one K-step ahead, and the
             // cross-group tap read from the partner buffer instead of carried in 64 registers - with a barrier before that
             // buffer's first rolling store.
-            constexpr int SUB = 4, RS = RW / SUB;   // 2-row sub-steps: 4-row ones spill (-15 %), 1-row ones expose more LDS round trips (-1 %)
+            constexpr int SUB = W8 ? 2 : 4, RS = RW / SUB;   // 2-row sub-steps: 4-row ones spill (-15 %), 1-row ones expose more LDS round trips (-1 %)
             const char *part = reinterpret_cast<const char *>(lds + ((cb + 1) & 1) * G::BUF);
-            if (NK == 0 && FETCH) h2_stage_load<KH, KW>(plan, nxt_grp, rl);   // 1x1 source, even group: only fetch the partner group
+            if (NK == 0 && FETCH) h2_stage_load<KH, KW, NTHR>(plan, nxt_grp, rl);   // 1x1 source, even group: only fetch the partner group
 #pragma unroll
             for (int ks = 0; ks < NK; ++ks) {
                 asm volatile("" : "+v"(tapsel));
@@ -233,9 +235,9 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
                         for (int nt = 0; nt < CW; ++nt) w0[nt] = w0n[nt];
 #pragma unroll
                         for (int nt = 0; nt < CW; ++nt) { w1n[nt] = wf[(1 * NT + nt) * 64]; w0n[nt] = wf[(0 * NT + nt) * 64]; }
-                        if (FETCH) h2_stage_load<KH, KW>(plan, nxt_grp, rl, ks * PER, (ks + 1) * PER);
+                        if (FETCH) h2_stage_load<KH, KW, NTHR>(plan, nxt_grp, rl, ks * PER, (ks + 1) * PER);
                         if (more && ks >= LAG)
-                            h2_stage_store<KH, KW>(plan, lds + ((cb + 1) & 1) * G::BUF, rs, (ks - LAG) * PER, (ks - LAG + 1) * PER);
+                            h2_stage_store<KH, KW, NTHR>(plan, lds + ((cb + 1) & 1) * G::BUF, rs, (ks - LAG) * PER, (ks - LAG + 1) * PER);
                     } else if (h == SUB - 1) {
 #pragma unroll
                         for (int nt = 0; nt < CW; ++nt) w1[nt] = w1n[nt];
@@ -258,7 +260,7 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
             }
         } else {
             if (NK == 0) {   // 1x1 source, even group: nothing to compute yet, only fetch the partner group
-                if (!(ABL & 1) && FETCH) h2_stage_load<KH, KW>(plan, nxt_grp, rl);
+                if (!(ABL & 1) && FETCH) h2_stage_load<KH, KW, NTHR>(plan, nxt_grp, rl);
             } else if (MODE == 2) {
                 // cross-group pair: lanes g < 2 still hold the even group's last tap (picked up before the barrier that ended
                 // it - that buffer is being overwritten by now), lanes g >= 2 read this group's last tap
@@ -317,12 +319,12 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
                 // a weight fragment requested after an HBM load cannot be used before that load has landed.  Here the next such
                 // fragment is the w1 request of the NEXT K-step, used two K-steps from now.
                 if (!(ABL & 1) && FETCH) {
-                    if (ABL & 32) { if (ks == 0) h2_stage_load<KH, KW>(plan, nxt_grp, rl); }
-                    else h2_stage_load<KH, KW>(plan, nxt_grp, rl, ks * PER, (ks + 1) * PER);
+                    if (ABL & 32) { if (ks == 0) h2_stage_load<KH, KW, NTHR>(plan, nxt_grp, rl); }
+                    else h2_stage_load<KH, KW, NTHR>(plan, nxt_grp, rl, ks * PER, (ks + 1) * PER);
                 }
                 // ... and the slice requested LAG K-steps ago goes to the partner LDS buffer, which nobody reads during this group
                 if (ROLL && more && !(ABL & 1) && ks >= LAG)
-                    h2_stage_store<KH, KW>(plan, lds + ((cb + 1) & 1) * G::BUF, rs, (ks - LAG) * PER, (ks - LAG + 1) * PER);
+                    h2_stage_store<KH, KW, NTHR>(plan, lds + ((cb + 1) & 1) * G::BUF, rs, (ks - LAG) * PER, (ks - LAG + 1) * PER);
                 __builtin_amdgcn_sched_barrier(0);
                 // phase B1: x0*w0, then x0 is free for the next K-step's pixels
 #pragma unroll
@@ -361,7 +363,7 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
         if (ABL & 128) { const unsigned long long t = h2_stamp(); t_k += t - tmark; tmark = t; }
         // the store goes to the buffer nobody reads during this group (the deferred tap travels in registers)
         if (more && !(ABL & 1))
-            h2_stage_store<KH, KW>(plan, lds + ((cb + 1) & 1) * G::BUF, rs, ROLL && NK > LAG ? (NK - LAG) * PER : 0);
+            h2_stage_store<KH, KW, NTHR>(plan, lds + ((cb + 1) & 1) * G::BUF, rs, ROLL && NK > LAG ? (NK - LAG) * PER : 0);
         if (ABL & 128) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t = h2_stamp(); t_s += t - tmark; tmark = t; }
         __syncthreads();
         if (ABL & 128) { const unsigned long long t = h2_stamp(); t_b += t - tmark; tmark = t; }
@@ -387,13 +389,13 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
     if ((ABL & 128) && dbg && threadIdx.x == 0) { dbg[0] = t_pro; dbg[1] = t_k; dbg[2] = t_s; dbg[3] = t_b; }
 }
 
-template <int NT, int ABL>
-__device__ __forceinline__ void h2_epilogue(const ConvX6Args &a, f32x4 (&acc)[WaveTile<NT>::RW][WaveTile<NT>::CW], int n, int ty, int tx);
+template <int NT, int ABL, bool W8 = false>
+__device__ __forceinline__ void h2_epilogue(const ConvX6Args &a, f32x4 (&acc)[WaveTile<NT, W8>::RW][WaveTile<NT, W8>::CW], int n, int ty, int tx);
 
-template <int KH, int KW, int NT, bool SC, int ABL = 0, bool LEAN = false>
-__global__ __launch_bounds__(256, NT == 4 && !LEAN ? 2 : 3) void conv_h2_kernel(ConvX6Args a)
+template <int KH, int KW, int NT, bool SC, int ABL = 0, bool LEAN = false, bool W8 = false>
+__global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : (NT == 4 && !LEAN ? 2 : 3)) void conv_h2_kernel(ConvX6Args a)
 {
-    typedef GeoH<KH, KW> G;
+    typedef GeoH<KH, KW, 16, W8 ? 512 : 256> G;
     __shared__ u32x4 lds[2 * G::BUF];
     const int tiles_x = a.W >> 4, tiles = tiles_x * (a.H >> 4);
     // XCD-aware tile order: workgroup ids go round-robin over the 8 XCDs (each with its own L2), so consecutive ids would put
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(256, NT == 4 && !LEAN ? 2 : 3) void conv_h2_kernel(
     if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
     const int n0 = bid / tiles, t = bid - n0 * tiles, ty = t / tiles_x, tx = t - ty * tiles_x;
     const int n = (ABL & 64) ? 0 : n0;   // timing-only build: every block's addresses collapse onto block 0 (L2-resident working set)
-    typedef WaveTile<NT> WT;
+    typedef WaveTile<NT, W8> WT;
     constexpr int RW = WT::RW, CW = WT::CW;
 
     f32x4 acc[RW][CW];
@@ -413,16 +415,16 @@ __global__ __launch_bounds__(256, NT == 4 && !LEAN ? 2 : 3) void conv_h2_kernel(
 
     const unsigned long long t_begin = (ABL & 128) ? h2_stamp() : 0;
     {
-        H2Carry<KH, KW, NT> carry;
-        h2_accumulate<KH, KW, NT, ABL, false, LEAN>(a.x, a.x_stride, a.w, a.Cin, a.H, a.W, n, ty, tx, lds, acc,
+        H2Carry<KH, KW, NT, W8> carry;
+        h2_accumulate<KH, KW, NT, ABL, false, LEAN, W8>(a.x, a.x_stride, a.w, a.Cin, a.H, a.W, n, ty, tx, lds, acc,
                                        a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr, carry, true, n, ty, tx);
     }
     const unsigned long long t_acc = (ABL & 128) ? h2_stamp() : 0;
     if (SC) {
-        H2Carry<1, 1, NT> carry;
-        h2_accumulate<1, 1, NT, 0, false, LEAN>(a.x_sc, a.sc_stride, a.w_sc, a.Csc, a.H, a.W, n, ty, tx, lds, acc, nullptr, carry, true, n, ty, tx);
+        H2Carry<1, 1, NT, W8> carry;
+        h2_accumulate<1, 1, NT, 0, false, LEAN, W8>(a.x_sc, a.sc_stride, a.w_sc, a.Csc, a.H, a.W, n, ty, tx, lds, acc, nullptr, carry, true, n, ty, tx);
     }
-    h2_epilogue<NT, ABL>(a, acc, n, ty, tx);
+    h2_epilogue<NT, ABL, W8>(a, acc, n, ty, tx);
     if ((ABL & 128) && a.dbg && threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // include the store acknowledgements in the epilogue span
         const unsigned long long t_end = h2_stamp();
@@ -465,10 +467,10 @@ __global__ __launch_bounds__(256, LEAN ? 3 : 2) void conv_h2_persist_kernel(Conv
     }
 }
 
-template <int NT, int ABL>
-__device__ __forceinline__ void h2_epilogue(const ConvX6Args &a, f32x4 (&acc)[WaveTile<NT>::RW][WaveTile<NT>::CW], int n, int ty, int tx)
+template <int NT, int ABL, bool W8>
+__device__ __forceinline__ void h2_epilogue(const ConvX6Args &a, f32x4 (&acc)[WaveTile<NT, W8>::RW][WaveTile<NT, W8>::CW], int n, int ty, int tx)
 {
-    typedef WaveTile<NT> WT;
+    typedef WaveTile<NT, W8> WT;
     constexpr int RW = WT::RW, CW = WT::CW;
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));   // opaque: in the persistent kernels nothing lane-dependent of the epilogue is hoisted out of the tile loop
@@ -600,6 +602,8 @@ static hipError_t launch_h2(hipStream_t s, const ConvX6Args &a)
             case 135: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 135>), dim3(grid), dim3(256), 0, s, a); break;
             default: PMP_H2_LAUNCH(4); break;
             }
+        } else if (KH == 3 && !a.x_sc && g_conv_variant == 7) {   // 512-thread workgroups (8 waves = 2 row halves x 4 cout groups), two per CU
+            hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 0, true, true>), dim3(grid), dim3(512), 0, s, a);
         } else if (KH > 1 && !a.x_sc && g_conv_variant != 3 && g_conv_variant != 4 && g_conv_variant != 5) {
             // default for the Cout = 64 layers without a shortcut source: the 168-VGPR form, three workgroups per CU
             // (3x3: -5.6 %, 5x5: -1.9 % against the two-workgroup form, which PMP_CONV_VARIANT=3 selects for A/B timing; the

@@ -88,12 +88,12 @@ __device__ __forceinline__ void store_split2_4_nt(unsigned short *p, size_t plan
 }
 
 // ---- geometry shared by conv_f16x3.hip and conv_f16x3_ws.hip
-template <int KH, int KW, int TR = 16>   // TR = output rows per workgroup tile (16 columns always)
+template <int KH, int KW, int TR = 16, int NTHR = 256>   // TR = output rows per workgroup tile (16 columns always), NTHR = threads that stage it
 struct GeoH {
     static constexpr int TH = TR + KH - 1, TW = 16 + KW - 1, TAPS = KH * KW, NKS = (TAPS + 1) / 2;
     static constexpr int PLANE = TH * TW * 2;            // 16-B pieces per split plane (32 B per pixel)
     static constexpr int PIECES = 2 * PLANE;             // per buffer
-    static constexpr int NLD = (PIECES + 255) / 256;
+    static constexpr int NLD = (PIECES + NTHR - 1) / NTHR;
     static constexpr int BUF = PIECES + 1;               // pieces reserved per LDS buffer: one spare slot, so that every staging thread
                                                          // stores all NLD of its pieces unconditionally (a conditional store lets hipcc
                                                          // sink the global load into the branch, next to its use, and wait for it there)
@@ -102,11 +102,12 @@ struct GeoH {
 // Wave tile: RW rows x CW cout groups of the workgroup's 16 rows x NT groups (4 waves).  At Cout >= 32 a wave takes 8 rows
 // and half (or all) of the cout groups: it then streams half of the weight bytes per MFMA from L2 - the vector-memory
 // path is the contended one here - and reads twice the pixel fragments from LDS, which has the headroom.
-template <int NT>
+template <int NT, bool W8 = false>   // W8: 512-thread workgroups, 8 waves = 2 row halves x 4 cout groups (Cout = 64 only)
 struct WaveTile {
+    static constexpr int WAVES = W8 ? 8 : 4;
     static constexpr int RW = NT == 4 ? 8 : 4;        // rows per wave (Cout <= 32: 4 rows - fewer registers, a third workgroup per CU)
     static constexpr int RSPLIT = 16 / RW;            // waves along the rows
-    static constexpr int CW = NT / (4 / RSPLIT);      // cout groups per wave (4 waves = RSPLIT x NT/CW)
+    static constexpr int CW = NT / (WAVES / RSPLIT);  // cout groups per wave (WAVES = RSPLIT x NT/CW)
 };
 
 // s_barrier after an LDS-only wait: global loads (weights, halo requests) stay in flight across it
