@@ -156,9 +156,9 @@ int pmp_ktime_get(pmp_ctx *ctx, int cls, int64_t *launches, double *ms, double *
 /* ---- measurement hook: selects the conv kernel build used by later launches (process-wide).
  *      fp32 datapath: 0 = un-pipelined kernel, 1 = software-pipelined (3 waves/SIMD), 2 = fully pipelined, 2 waves/SIMD
  *      (default).  f16x3 datapath, Cout = 64 kernels without shortcut source (conv_f16x3.hip): 3 = two workgroups per
- *      CU (236-256 VGPRs, 8-row pixel fragments), 4 = that form made persistent, 5 = the default form made persistent (3x3 only), 7 = 512-thread workgroups (3x3 only), anything else = three workgroups per CU
+ *      CU (236-256 VGPRs, 8-row pixel fragments), 4 = that form made persistent, 5 = the default form made persistent (3x3 only), 7 = 512-thread workgroups, 8 = 16-row x 1-cout-group wave tiles (3x3 only), anything else = three workgroups per CU
  *      (168 VGPRs, default).  10 + bits = timing-only ablation builds (wrong results; tools/conv_x6_bench.py).
- *      Variants 0..7 compute bit-identical results per datapath; tools/conv_ab.py uses this for in-process A/B timing. ---- */
+ *      Variants 0..8 compute bit-identical results per datapath; tools/conv_ab.py uses this for in-process A/B timing. ---- */
 int pmp_debug_set_conv_variant(int variant);
 
 /* ---- test hook (host only, no GPU needed): the f16x3 weight packing of one OIHW conv tensor (conv_f16x3.hip).

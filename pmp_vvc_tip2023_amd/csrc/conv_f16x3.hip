@@ -92,20 +92,20 @@ __device__ __forceinline__ void h2_stage_store(const StagePlanH<KH, KW, NTHR> &p
 
 // State that outlives one tile in the persistent kernel (CHAIN): the weight fragments of the next K-step - the stream wraps
 // around to the first K-step at the end of a tile - and the staging plan of the tile whose first halo group is in LDS.
-template <int KH, int KW, int NT, bool W8 = false>
+template <int KH, int KW, int NT, int W8 = 0>
 struct H2Carry {
     static constexpr int CW = WaveTile<NT, W8>::CW;
     f16x8 w0[CW], w1[CW], w0n[CW], w1n[CW], w0nn[CW];
-    StagePlanH<KH, KW, W8 ? 512 : 256> plan;
+    StagePlanH<KH, KW, W8 == 1 ? 512 : 256> plan;
 };
 
-template <int KH, int KW, int NT, int ABL = 0, bool CHAIN = false, bool LEAN = false, bool W8 = false>
+template <int KH, int KW, int NT, int ABL = 0, bool CHAIN = false, bool LEAN = false, int W8 = 0>
 __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__ x, size_t plane_stride,
                                               const unsigned short *__restrict__ wpk, int C, int H, int W, int n, int ty,
                                               int tx, u32x4 *lds, f32x4 (&acc)[WaveTile<NT, W8>::RW][WaveTile<NT, W8>::CW],
                                               unsigned long long *dbg, H2Carry<KH, KW, NT, W8> &c, bool first, int n2, int ty2, int tx2)
 {
-    constexpr int NTHR = W8 ? 512 : 256;
+    constexpr int NTHR = W8 == 1 ? 512 : 256;
     unsigned long long t_pro = 0, t_k = 0, t_s = 0, t_b = 0, tmark = 0;   // diagnostic accumulators (ABL & 128)
     if (ABL & 128) tmark = h2_stamp();
     typedef GeoH<KH, KW, 16, NTHR> G;
@@ -202,7 +202,7 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
             // waves of the SIMD cover the LDS round trip), both weight splits double-buffered one K-step ahead, and the
             // cross-group tap read from the partner buffer instead of carried in 64 registers - with a barrier before that
             // buffer's first rolling store.
-            constexpr int SUB = W8 ? 2 : 4, RS = RW / SUB;   // 2-row sub-steps: 4-row ones spill (-15 %), 1-row ones expose more LDS round trips (-1 %)
+            constexpr int RS = W8 == 1 ? 4 : 2, SUB = RW / RS;   // 2-row sub-steps: 4-row ones spill (-15 %), 1-row ones expose more LDS round trips (-1 %)
             const char *part = reinterpret_cast<const char *>(lds + ((cb + 1) & 1) * G::BUF);
             if (NK == 0 && FETCH) h2_stage_load<KH, KW, NTHR>(plan, nxt_grp, rl);   // 1x1 source, even group: only fetch the partner group
 #pragma unroll
@@ -389,13 +389,13 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
     if ((ABL & 128) && dbg && threadIdx.x == 0) { dbg[0] = t_pro; dbg[1] = t_k; dbg[2] = t_s; dbg[3] = t_b; }
 }
 
-template <int NT, int ABL, bool W8 = false>
+template <int NT, int ABL, int W8 = 0>
 __device__ __forceinline__ void h2_epilogue(const ConvX6Args &a, f32x4 (&acc)[WaveTile<NT, W8>::RW][WaveTile<NT, W8>::CW], int n, int ty, int tx);
 
-template <int KH, int KW, int NT, bool SC, int ABL = 0, bool LEAN = false, bool W8 = false>
-__global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : (NT == 4 && !LEAN ? 2 : 3)) void conv_h2_kernel(ConvX6Args a)
+template <int KH, int KW, int NT, bool SC, int ABL = 0, bool LEAN = false, int W8 = 0>
+__global__ __launch_bounds__(W8 == 1 ? 512 : 256, W8 == 1 ? 4 : (NT == 4 && !LEAN ? 2 : 3)) void conv_h2_kernel(ConvX6Args a)
 {
-    typedef GeoH<KH, KW, 16, W8 ? 512 : 256> G;
+    typedef GeoH<KH, KW, 16, W8 == 1 ? 512 : 256> G;
     __shared__ u32x4 lds[2 * G::BUF];
     const int tiles_x = a.W >> 4, tiles = tiles_x * (a.H >> 4);
     // XCD-aware tile order: workgroup ids go round-robin over the 8 XCDs (each with its own L2), so consecutive ids would put
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256, LEAN ? 3 : 2) void conv_h2_persist_kernel(Conv
     }
 }
 
-template <int NT, int ABL, bool W8>
+template <int NT, int ABL, int W8>
 __device__ __forceinline__ void h2_epilogue(const ConvX6Args &a, f32x4 (&acc)[WaveTile<NT, W8>::RW][WaveTile<NT, W8>::CW], int n, int ty, int tx)
 {
     typedef WaveTile<NT, W8> WT;
@@ -602,8 +602,10 @@ static hipError_t launch_h2(hipStream_t s, const ConvX6Args &a)
             case 135: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 135>), dim3(grid), dim3(256), 0, s, a); break;
             default: PMP_H2_LAUNCH(4); break;
             }
+        } else if (KH == 3 && !a.x_sc && g_conv_variant == 8) {   // A/B: 4 waves x (16 rows, 1 cout group), three workgroups per CU
+            hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 0, true, 2>), dim3(grid), dim3(256), 0, s, a);
         } else if (KH == 3 && !a.x_sc && g_conv_variant == 7) {   // 512-thread workgroups (8 waves = 2 row halves x 4 cout groups), two per CU
-            hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 0, true, true>), dim3(grid), dim3(512), 0, s, a);
+            hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 0, true, 1>), dim3(grid), dim3(512), 0, s, a);
         } else if (KH > 1 && !a.x_sc && g_conv_variant != 3 && g_conv_variant != 4 && g_conv_variant != 5) {
             // default for the Cout = 64 layers without a shortcut source: the 168-VGPR form, three workgroups per CU
             // (3x3: -5.6 %, 5x5: -1.9 % against the two-workgroup form, which PMP_CONV_VARIANT=3 selects for A/B timing; the

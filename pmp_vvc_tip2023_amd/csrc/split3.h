@@ -102,10 +102,10 @@ struct GeoH {
 // Wave tile: RW rows x CW cout groups of the workgroup's 16 rows x NT groups (4 waves).  At Cout >= 32 a wave takes 8 rows
 // and half (or all) of the cout groups: it then streams half of the weight bytes per MFMA from L2 - the vector-memory
 // path is the contended one here - and reads twice the pixel fragments from LDS, which has the headroom.
-template <int NT, bool W8 = false>   // W8: 512-thread workgroups, 8 waves = 2 row halves x 4 cout groups (Cout = 64 only)
+template <int NT, int W8 = 0>   // W8 = 1: 512-thread workgroups, 8 waves = 2 row halves x 4 cout groups; 2: 4 waves x (16 rows, 1 cout group) (Cout = 64 only)
 struct WaveTile {
-    static constexpr int WAVES = W8 ? 8 : 4;
-    static constexpr int RW = NT == 4 ? 8 : 4;        // rows per wave (Cout <= 32: 4 rows - fewer registers, a third workgroup per CU)
+    static constexpr int WAVES = W8 == 1 ? 8 : 4;
+    static constexpr int RW = W8 == 2 ? 16 : NT == 4 ? 8 : 4;   // W8 == 2: 4 waves, each all 16 rows x one cout group        // rows per wave (Cout <= 32: 4 rows - fewer registers, a third workgroup per CU)
                                                       // (W8 with 4 rows x 2 cout groups per wave - twice the weight bytes per MFMA - is 3 % slower than 8 x 1)
     static constexpr int RSPLIT = 16 / RW;            // waves along the rows
     static constexpr int CW = NT / (WAVES / RSPLIT);  // cout groups per wave (WAVES = RSPLIT x NT/CW)
