@@ -72,7 +72,7 @@ __device__ __forceinline__ void h2_stage_load(const StagePlanH<KH, KW, NTHR> &p,
 #pragma unroll
     for (int k = 0; k < GeoH<KH, KW, 16, NTHR>::NLD; ++k) {
         if (k < k0 || k >= k1) continue;   // folds away: callers pass constants into unrolled code
-        r[k] = *reinterpret_cast<const u32x4 *>(grp + p.off[k]);
+        r[k] = *reinterpret_cast<const u32x4 *>(grp + p.off[k]);   // default cache policy: the non-temporal hint measured 1 % slower
     }
 }
 
