@@ -75,6 +75,29 @@ def test_logits_vs_oracle_fresh_inputs_and_chunking(eng, comp):
     assert np.array_equal(qt, qt2) and np.array_equal(bt, bt2) and np.array_equal(dire, dire2)
 
 
+@pytest.mark.parametrize("shape", [(8, 32, 32, 48, 64, 3), (8, 32, 32, 16, 64, 3), (4, 16, 16, 80, 64, 5), (8, 16, 16, 96, 32, 3),
+                                   (4, 16, 16, 48, 16, 3), (8, 32, 32, 32, 64, 1), (4, 48, 32, 64, 64, 3)])
+def test_conv_kernel_shapes_beyond_the_nets(eng, shape):
+    """Convolution shapes the four nets never launch (odd channel-group counts: the unpaired K order of the split kernels;
+    1x1; non-square maps): the split datapaths against the exact fp32 MFMA kernel on the same random tensors
+    (pmp_debug_conv_bench, include/pmp.h)."""
+    import ctypes as C
+    if eng.get_precision() == "fp32":
+        pytest.skip("the fp32 kernel is the reference of this comparison")
+    n, h, w, ci, co, k = shape
+    a, b, d, r = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+    eng._ck(eng.lib.pmp_debug_conv_bench(eng.h, n, h, w, ci, co, k, 1, C.byref(a), C.byref(b), C.byref(d), C.byref(r)))
+    assert r.value > 0.5 and d.value < 1e-4 * max(1.0, r.value), (shape, d.value, r.value)
+    if eng.get_precision() == "f16x3" and co == 64 and k == 3:   # the alternative forms of the 3x3 Cout = 64 kernel on the same shape
+        for variant in (3, 7, 8):
+            eng.lib.pmp_debug_set_conv_variant(variant)
+            try:
+                eng._ck(eng.lib.pmp_debug_conv_bench(eng.h, n, h, w, ci, co, k, 1, C.byref(a), C.byref(b), C.byref(d), C.byref(r)))
+            finally:
+                eng.lib.pmp_debug_set_conv_variant(2)
+            assert d.value < 1e-4 * max(1.0, r.value), (shape, variant, d.value, r.value)
+
+
 def test_default_chunk_boundary(eng):
     """More blocks than one library pass (default chunk 4096): the ragged second pass gives what a call on those blocks alone gives."""
     from pmp_vvc_tip2023_amd import synth
