@@ -392,7 +392,60 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
 template <int NT, int ABL, int W8 = 0>
 __device__ __forceinline__ void h2_epilogue(const ConvX6Args &a, f32x4 (&acc)[WaveTile<NT, W8>::RW][WaveTile<NT, W8>::CW], int n, int ty, int tx);
 
-template <int KH, int KW, int NT, bool SC, int ABL = 0, bool LEAN = false, int W8 = 0>
+// The 1x1 shortcut source of a Cout = 64 block has 32 channels in every net (RB(32,64,k)): two channel groups = ONE K-step.
+// Instead of the general staging pipeline (five barriers, its own plan, weights and staging registers) the whole 16x16 x 32 ch
+// tile goes to LDS at once - no halo - and each wave runs that K-step in 2-row sub-steps.  Same MFMA order per accumulator as
+// the general pass (x0*w1, x0*w0, x1*w0 after the main pass), so the results are bit-identical.
+template <int NT, int W8>
+__device__ __forceinline__ void h2_shortcut32(const ConvX6Args &a, int n, int ty, int tx, u32x4 *lds,
+                                              f32x4 (&acc)[WaveTile<NT, W8>::RW][WaveTile<NT, W8>::CW])
+{
+    typedef WaveTile<NT, W8> WT;
+    constexpr int RW = WT::RW, CW = WT::CW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, xl = lane & 15, g = lane >> 4;
+    const int rh = wave % WT::RSPLIT, ch = wave / WT::RSPLIT;
+    const int W = a.W;
+    const size_t grp_sz = (size_t)a.H * W * 16;
+    const unsigned short *base = a.x_sc + (size_t)n * 2 * grp_sz + ((size_t)(ty * 16) * W + tx * 16) * 16;
+    __syncthreads();   // every wave is done with the main pass's halo tiles
+    u32x4 r[8];        // piece i = [group][plane][pixel][half]: 2 x 2 x 256 x 2 pieces of 16 B
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = tid + k * 256, grp = i >> 10, plane = (i >> 9) & 1, j = i & 511, px = j >> 1, half = j & 1;
+        r[k] = *reinterpret_cast<const u32x4 *>(base + plane * a.sc_stride + grp * grp_sz + ((size_t)(px >> 4) * W + (px & 15)) * 16 + half * 8);
+    }
+    const f16x8 *wl = reinterpret_cast<const f16x8 *>(a.w_sc) + lane + ch * CW * 64;
+    f16x8 w0[CW], w1[CW];
+#pragma unroll
+    for (int nt = 0; nt < CW; ++nt) { w0[nt] = wl[(0 * NT + nt) * 64]; w1[nt] = wl[(1 * NT + nt) * 64]; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) lds[tid + k * 256] = r[k];
+    __syncthreads();
+    const char *px = reinterpret_cast<const char *>(lds) + (g >> 1) * 16384 + ((rh * RW * 16 + xl) * 2 + (g & 1)) * 16;
+#pragma unroll
+    for (int h = 0; h < RW / 2; ++h) {
+        f16x8 xa[2], xb[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            xa[m] = *reinterpret_cast<const f16x8 *>(px + (h * 2 + m) * 16 * 32);
+            xb[m] = *reinterpret_cast<const f16x8 *>(px + 8192 + (h * 2 + m) * 16 * 32);
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int nt = 0; nt < CW; ++nt) acc[h * 2 + m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[nt], xa[m], acc[h * 2 + m][nt], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int nt = 0; nt < CW; ++nt) acc[h * 2 + m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[nt], xa[m], acc[h * 2 + m][nt], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int nt = 0; nt < CW; ++nt) acc[h * 2 + m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[nt], xb[m], acc[h * 2 + m][nt], 0, 0, 0);
+    }
+}
+
+template <int KH, int KW, int NT, int SC, int ABL = 0, bool LEAN = false, int W8 = 0>   // SC: 0 none, 1 general 1x1 shortcut pass, 2 the 32-channel one
 __global__ __launch_bounds__(W8 == 1 ? 512 : 256, W8 == 1 ? 4 : (NT == 4 && !LEAN ? 2 : 3)) void conv_h2_kernel(ConvX6Args a)
 {
     typedef GeoH<KH, KW, 16, W8 == 1 ? 512 : 256> G;
@@ -420,7 +473,9 @@ __global__ __launch_bounds__(W8 == 1 ? 512 : 256, W8 == 1 ? 4 : (NT == 4 && !LEA
                                        a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr, carry, true, n, ty, tx);
     }
     const unsigned long long t_acc = (ABL & 128) ? h2_stamp() : 0;
-    if (SC) {
+    if (SC == 2) {
+        h2_shortcut32<NT, W8>(a, n, ty, tx, lds, acc);
+    } else if (SC) {
         H2Carry<1, 1, NT, W8> carry;
         h2_accumulate<1, 1, NT, 0, false, LEAN, W8>(a.x_sc, a.sc_stride, a.w_sc, a.Csc, a.H, a.W, n, ty, tx, lds, acc, nullptr, carry, true, n, ty, tx);
     }
@@ -571,7 +626,10 @@ static hipError_t launch_h2(hipStream_t s, const ConvX6Args &a)
     case 1: PMP_H2_LAUNCH(1); break;
     case 2: PMP_H2_LAUNCH(2); break;
     case 4:
-        if (KH == 5 && !a.x_sc && g_conv_variant >= 10) {   // timing-only ablation builds, 5x5
+        if (KH > 1 && a.x_sc && a.Csc == 32 && g_conv_variant != 3) {   // variant 3: the general shortcut pass, for A/B timing
+            // two workgroups per CU: in the 168-VGPR form these kernels measure the same (5x5 class 5.94 vs 5.95 ms per 1024 blocks)
+            hipLaunchKernelGGL((conv_h2_kernel<KH, KW, 4, 2>), dim3(grid), dim3(256), 0, s, a);
+        } else if (KH == 5 && !a.x_sc && g_conv_variant >= 10) {   // timing-only ablation builds, 5x5
             switch (g_conv_variant - 10) {
             case 1: hipLaunchKernelGGL((conv_h2_kernel<5, 5, 4, false, 1>), dim3(grid), dim3(256), 0, s, a); break;
             case 2: hipLaunchKernelGGL((conv_h2_kernel<5, 5, 4, false, 2>), dim3(grid), dim3(256), 0, s, a); break;
