@@ -10,7 +10,7 @@ if os.path.isfile("profiles/pmc_traffic.json"):
     out = json.load(open("profiles/pmc_traffic.json"))
 for k, v in src.items():
     mode = "fp32" if k.startswith("conv_mfma_kernel<3, 3, 4") else ("bf16x6" if k.startswith("conv_x6_kernel<3, 3, 4") else
-                                                                      ("f16x3" if k.startswith("conv_h2_kernel<3, 3, 4, sc=false") else None))
+                                                                      ("f16x3" if k.startswith(("conv_h2_kernel<3, 3, 4, sc=false", "conv_h2_kernel<3, 3, 4, sc=0")) else None))
     if mode and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         out["conv_mfma_3x3_c64:" + mode] = round((2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0)
         out["_blocks_per_launch:" + mode] = int(sys.argv[2]) if len(sys.argv) > 2 else 4096   # blocks per launch of the profiled run (bench.py scales)
