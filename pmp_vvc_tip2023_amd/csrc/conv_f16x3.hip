@@ -375,7 +375,8 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
     typedef std::integral_constant<int, 0> T0;
     typedef std::integral_constant<int, 1> T1;
     typedef std::integral_constant<int, 2> T2;
-    if (paired) {   // the last two groups are peeled: they have nothing (or less) to request
+    if (paired) {   // the last two groups are peeled: they have nothing (or less) to request (peeling all four groups of a
+                    // 64-channel input, to lose the register shuffles at the loop's back edge, gains nothing and spills more)
         for (int cb = 0; cb + 2 < CB; cb += 2) {
             group(M1{}, T0{}, cb);
             group(M2{}, T0{}, cb + 1);
