@@ -53,7 +53,7 @@ def cpu_baseline(sample_blocks, seed, eng=None):
     ncpu = os.cpu_count() or 1
     y, _, _ = synth.recipe_r_blocks(sample_blocks, seed)
     wq, _ = W.load_net_weights("Luma_Q", 22)
-    wbd, _ = W.load_net_weights("Luma_MSBD", 22)
+    wbd, _ = W.load_net_weights("Luma_MSBD", 22, allow_synthetic=True)
     x = O.luma_input(y)
     # torch's CPU convs do not scale to hundreds of threads on 64x64 maps: calibrate the thread count on 8 blocks
     best = (None, 1e30)
@@ -143,7 +143,7 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from pmp_vvc_tip2023_amd import engine, synth
-    eng = engine.Engine(local_rank)
+    eng = engine.Engine(local_rank, allow_synthetic_mtt=True)
     if args.chunk:
         eng.set_chunk(args.chunk)
     eng.set_precision(args.precision)

@@ -124,8 +124,8 @@ int pmp_cut_blocks_device(pmp_ctx *ctx, const void *d_y, const void *d_u, const 
  *      integer per line.  Host-side (file I/O); inputs are per-block arrays in block order. ---------------- */
 int pmp_write_partition_file(const char *path, int frames, int height, int width, const uint8_t *hor,
                              const uint8_t *ver, const uint8_t *qt_u8, const int8_t *dire_i8);
-/* Same bytes into memory: returns the byte count (or a negative error).  buf == NULL returns the exact size; when
- * filling, give the buffer 96 bytes of slack (cap >= size + 96): room for a whole row is checked before it is written. */
+/* Same bytes into memory: returns the byte count (or a negative error).  buf == NULL returns the exact size; a buffer of
+ * exactly that size is enough (cap < size: PMP_E_INVALID, nothing beyond buf[cap-1] is ever written). */
 int64_t pmp_format_partition_text(int frames, int height, int width, const uint8_t *hor, const uint8_t *ver,
                                   const uint8_t *qt_u8, const int8_t *dire_i8, char *buf, int64_t cap);
 

@@ -5,6 +5,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpmp_hip.so")
+ABL_LIB_PATH = os.path.join(_HERE, "libpmp_hip_abl.so")            # make abl: measurement build with timing-only kernels (tools/ only)
+HOSTASAN_LIB_PATH = os.path.join(_HERE, "libpmp_hostasan.so")      # make hostasan: host-only units under ASan/UBSan (tests only)
 
 PMP_LUMA, PMP_CHROMA = 0, 1
 NET_IDS = {"Luma_Q": 0, "Luma_MSBD": 1, "Chroma_Q": 2, "Chroma_MSBD": 3}
@@ -59,19 +61,30 @@ SIGNATURES = {
 _lib = None
 
 
-def load():
-    """Load libpmp_hip.so.  Fails loudly when the extension has not been built: there is no fallback path."""
+def open_library(path, subset=False):
+    """dlopen a build of the C ABI and type its entry points.  subset=True accepts a library that exports only some of
+    include/pmp.h (the host-only sanitizer build); the product library must export all of it."""
+    if not os.path.isfile(path):
+        raise ImportError("%s is missing - build it with `make -C %s` (or __graft_entry__.build())"
+                          % (path, os.path.join(_HERE, "csrc")))
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        if subset and not hasattr(lib, name):
+            continue
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def load(path=None):
+    """Load libpmp_hip.so (or, for tools/ and tests, the build at `path` - before anything else loaded the library).
+    Fails loudly when the extension has not been built: there is no fallback path."""
     global _lib
     if _lib is None:
-        if not os.path.isfile(LIB_PATH):
-            raise ImportError("%s is missing - build it with `make -C %s` (or __graft_entry__.build())"
-                              % (LIB_PATH, os.path.join(_HERE, "csrc")))
-        lib = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(lib, name)
-            fn.restype = res
-            fn.argtypes = args
-        _lib = lib
+        _lib = open_library(path or LIB_PATH)
+    elif path is not None and os.path.abspath(path) != os.path.abspath(_lib._name):
+        raise RuntimeError("a different build of the library is already loaded: %s" % _lib._name)
     return _lib
 
 

@@ -331,6 +331,7 @@ static hipError_t launch_x6(hipStream_t s, const ConvX6Args &a)
     case 1: hipLaunchKernelGGL((conv_x6_kernel<KH, KW, 1>), dim3(grid), dim3(256), 0, s, a); break;
     case 2: hipLaunchKernelGGL((conv_x6_kernel<KH, KW, 2>), dim3(grid), dim3(256), 0, s, a); break;
     case 4:
+#ifdef PMP_ABLATION   // timing-only builds (wrong results): only in libpmp_hip_abl.so, never in the product library
         if (KH == 3 && g_conv_variant >= 10) {  // timing-only ablation builds (tools/conv_x6_bench.py)
             switch (g_conv_variant - 10) {
             case 1: hipLaunchKernelGGL((conv_x6_kernel<3, 3, 4, 1>), dim3(grid), dim3(256), 0, s, a); break;
@@ -346,7 +347,9 @@ static hipError_t launch_x6(hipStream_t s, const ConvX6Args &a)
             case 200: hipLaunchKernelGGL((conv_x6_kernel<3, 3, 4, 256>), dim3(grid), dim3(256), 0, s, a); break;
             default: hipLaunchKernelGGL((conv_x6_kernel<KH, KW, 4>), dim3(grid), dim3(256), 0, s, a); break;
             }
-        } else
+            break;
+        }
+#endif
             hipLaunchKernelGGL((conv_x6_kernel<KH, KW, 4>), dim3(grid), dim3(256), 0, s, a);
         break;
     default: return hipErrorInvalidValue;

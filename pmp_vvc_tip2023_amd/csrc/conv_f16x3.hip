@@ -630,6 +630,7 @@ static hipError_t launch_h2(hipStream_t s, const ConvX6Args &a)
         if (KH > 1 && a.x_sc && a.Csc == 32 && g_conv_variant != 3) {   // variant 3: the general shortcut pass, for A/B timing
             // two workgroups per CU: in the 168-VGPR form these kernels measure the same (5x5 class 5.94 vs 5.95 ms per 1024 blocks)
             hipLaunchKernelGGL((conv_h2_kernel<KH, KW, 4, 2>), dim3(grid), dim3(256), 0, s, a);
+#ifdef PMP_ABLATION   // timing-only builds (wrong results): only in libpmp_hip_abl.so, never in the product library
         } else if (KH == 5 && !a.x_sc && g_conv_variant >= 10) {   // timing-only ablation builds, 5x5
             switch (g_conv_variant - 10) {
             case 1: hipLaunchKernelGGL((conv_h2_kernel<5, 5, 4, false, 1>), dim3(grid), dim3(256), 0, s, a); break;
@@ -661,6 +662,7 @@ static hipError_t launch_h2(hipStream_t s, const ConvX6Args &a)
             case 135: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 135>), dim3(grid), dim3(256), 0, s, a); break;
             default: PMP_H2_LAUNCH(4); break;
             }
+#endif
         } else if (KH == 3 && !a.x_sc && g_conv_variant == 8) {   // A/B: 4 waves x (16 rows, 1 cout group), three workgroups per CU
             hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 0, true, 2>), dim3(grid), dim3(256), 0, s, a);
         } else if (KH == 3 && !a.x_sc && g_conv_variant == 7) {   // 512-thread workgroups (8 waves = 2 row halves x 4 cout groups), two per CU

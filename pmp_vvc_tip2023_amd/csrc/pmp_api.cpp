@@ -13,13 +13,10 @@
 
 namespace pmp {
 
-static thread_local std::string g_err;
-
 int set_err(pmp_ctx *c, int code, const std::string &msg)
 {
     if (c) c->err = msg;
-    g_err = msg;
-    return code;
+    return set_err_global(code, msg);   // host_emit.cpp: the calling thread's context-less error string
 }
 
 int hip_fail(pmp_ctx *c, hipError_t e, const char *what)
@@ -157,9 +154,16 @@ using namespace pmp;
 
 extern "C" {
 
-const char *pmp_version(void) { return "pmp-hip 0.2 (gfx950; fp32 MFMA + bf16x6 split MFMA)"; }
+const char *pmp_version(void)
+{
+#ifdef PMP_ABLATION
+    return "pmp-hip 0.3-abl (gfx950; f16x3 / bf16x6 split MFMA + fp32 MFMA; MEASUREMENT BUILD with timing-only kernels)";
+#else
+    return "pmp-hip 0.3 (gfx950; f16x3 default, bf16x6 and fp32 MFMA datapaths)";
+#endif
+}
 
-const char *pmp_last_error(const pmp_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+const char *pmp_last_error(const pmp_ctx *ctx) { return ctx ? ctx->err.c_str() : global_err(); }
 
 int pmp_create(int device_id, pmp_ctx **out)
 {
@@ -173,7 +177,9 @@ int pmp_create(int device_id, pmp_ctx **out)
     if ((e = hipSetDevice(device_id)) != hipSuccess) return hip_fail(nullptr, e, "hipSetDevice");
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return hip_fail(nullptr, e, "hipGetDeviceProperties");
-    if (const char *v = getenv("PMP_CONV_VARIANT")) g_conv_variant = atoi(v);   // debug knob, see pmp_debug_set_conv_variant
+#ifdef PMP_ABLATION   // measurement library only (libpmp_hip_abl.so): the product library reads no environment variable
+    if (const char *v = getenv("PMP_CONV_VARIANT")) g_conv_variant = atoi(v);
+#endif
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
         return set_err(nullptr, PMP_E_NODEVICE, std::string("pmp_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName);
     pmp_ctx *c = new (std::nothrow) pmp_ctx();
@@ -402,121 +408,17 @@ int pmp_cut_blocks(pmp_ctx *c, const void *y, const void *u, const void *v, int 
     return sync(c);
 }
 
-// ---- PartitionMat text (Map2Partition.py:385-412) ---------------------------------------------------------
-// Emission is the host-side hot spot of the path: 645 k lines per 1080p frame and file.  Values are in
-// {-1, 0, 1, 2, 3}, so a line is "d\n" or "-1\n": 16 values of one block row are contiguous in the per-block arrays and are
-// expanded with one 16-bit store each (an unconditional '-' is written first and kept only for negative values).
-static inline char *emit_u8_row(char *p, const uint8_t *v, int count)
-{
-    unsigned m = 0;
-    for (int i = 0; i < count; ++i) m |= v[i];
-    if (m < 8) {   // every value is a single digit: fixed 2 bytes per value, no branches
-        for (int i = 0; i < count; ++i) { p[2 * i] = (char)('0' + v[i]); p[2 * i + 1] = '\n'; }
-        return p + 2 * count;
-    }
-    for (int i = 0; i < count; ++i) {
-        const unsigned d = v[i];
-        if (d < 10) { p[0] = (char)('0' + d); p[1] = '\n'; p += 2; }
-        else { p += snprintf(p, 8, "%u\n", d); }   // never produced by the path; kept for arbitrary caller data
-    }
-    return p;
-}
-
-static inline char *emit_i8_row(char *p, const int8_t *v, int count)
-{
-    for (int i = 0; i < count; ++i) {
-        const int d = v[i];
-        p[0] = '-';
-        p += d < 0;
-        const int a = d < 0 ? -d : d;
-        if (a < 10) { p[0] = (char)('0' + a); p[1] = '\n'; p += 2; }
-        else { p += snprintf(p, 8, "%d\n", a); }
-    }
-    return p;
-}
-
-int64_t pmp_format_partition_text(int frames, int H, int W, const uint8_t *hor, const uint8_t *ver, const uint8_t *qt_u8,
-                                  const int8_t *dire, char *buf, int64_t cap)
-{
-    if (frames < 0 || H < 0 || W < 0 || !hor || !ver || !qt_u8 || !dire) return set_err(nullptr, PMP_E_INVALID, "pmp_format_partition_text: bad arguments");
-    const int bh = H / 64, bw = W / 64, R = 16 * bh;
-    const int64_t nblk = (int64_t)frames * bh * bw;
-    if (!buf) {   // exact size: 2 bytes per value, +1 per negative direction, +digits beyond one for values >= 10
-        int64_t need = nblk * (256 + 256 + 64 + 768) * 2, neg = 0;
-        int amax = 0;
-        for (int64_t i = 0; i < nblk * 768; ++i) { neg += dire[i] < 0; const int a = dire[i] < 0 ? -dire[i] : dire[i]; amax = a > amax ? a : amax; }
-        unsigned umax = 0;
-        for (int64_t i = 0; i < nblk * 256; ++i) { umax = hor[i] > umax ? hor[i] : umax; umax = ver[i] > umax ? ver[i] : umax; }
-        for (int64_t i = 0; i < nblk * 64; ++i) umax = qt_u8[i] > umax ? qt_u8[i] : umax;
-        need += neg;
-        if (amax >= 10 || umax >= 10) {   // never on the path's own data; exact for arbitrary caller data
-            for (int64_t i = 0; i < nblk * 768; ++i) { const int a = dire[i] < 0 ? -dire[i] : dire[i]; need += (a >= 10) + (a >= 100); }
-            for (int64_t i = 0; i < nblk * 256; ++i) need += (hor[i] >= 10) + (hor[i] >= 100) + (ver[i] >= 10) + (ver[i] >= 100);
-            for (int64_t i = 0; i < nblk * 64; ++i) need += (qt_u8[i] >= 10) + (qt_u8[i] >= 100);
-        }
-        return need;
-    }
-    // the caller sized the buffer with the call above; a row of 16 values needs at most 16 * 5 bytes
-    char *p = buf, *end = buf + cap;
-    for (int f = 0; f < frames; ++f) {
-        const int64_t base = (int64_t)f * bh * bw;
-        for (int plane = 0; plane < 2; ++plane) {
-            const uint8_t *src = plane ? ver : hor;
-            for (int r = 0; r < R; ++r)
-                for (int bx = 0; bx < bw; ++bx) {
-                    if (end - p < 80) return set_err(nullptr, PMP_E_INVALID, "pmp_format_partition_text: buffer too small");
-                    p = emit_u8_row(p, src + (base + (int64_t)(r >> 4) * bw + bx) * 256 + (r & 15) * 16, 16);
-                }
-        }
-        for (int r = 0; r < R / 2; ++r)
-            for (int bx = 0; bx < bw; ++bx) {
-                if (end - p < 40) return set_err(nullptr, PMP_E_INVALID, "pmp_format_partition_text: buffer too small");
-                p = emit_u8_row(p, qt_u8 + (base + (int64_t)(r >> 3) * bw + bx) * 64 + (r & 7) * 8, 8);
-            }
-        for (int k = 0; k < 3; ++k)
-            for (int r = 0; r < R; ++r)
-                for (int bx = 0; bx < bw; ++bx) {
-                    if (end - p < 80) return set_err(nullptr, PMP_E_INVALID, "pmp_format_partition_text: buffer too small");
-                    p = emit_i8_row(p, dire + (base + (int64_t)(r >> 4) * bw + bx) * 768 + k * 256 + (r & 15) * 16, 16);
-                }
-    }
-    return p - buf;
-}
-
-int pmp_write_partition_file(const char *path, int frames, int H, int W, const uint8_t *hor, const uint8_t *ver,
-                             const uint8_t *qt_u8, const int8_t *dire)
-{
-    if (!path) return set_err(nullptr, PMP_E_INVALID, "pmp_write_partition_file: null path");
-    const int64_t need = pmp_format_partition_text(frames, H, W, hor, ver, qt_u8, dire, nullptr, 0);
-    if (need < 0) return (int)need;
-    std::unique_ptr<char[]> buf(new (std::nothrow) char[(size_t)need + 96]);   // slack: room for one more row, see pmp.h
-    if (!buf) return set_err(nullptr, PMP_E_NOMEM, "pmp_write_partition_file: out of host memory");
-    if (need && pmp_format_partition_text(frames, H, W, hor, ver, qt_u8, dire, buf.get(), need + 96) != need)
-        return set_err(nullptr, PMP_E_INVALID, "pmp_write_partition_file: formatting failed");
-    FILE *fp = fopen(path, "wb");
-    if (!fp) return set_err(nullptr, PMP_E_IO, std::string("cannot open ") + path);
-    const size_t wr = need ? fwrite(buf.get(), 1, (size_t)need, fp) : 0;
-    const int cl = fclose(fp);
-    if (wr != (size_t)need || cl != 0) return set_err(nullptr, PMP_E_IO, std::string("short write to ") + path);
-    return PMP_OK;
-}
-
 int pmp_debug_set_conv_variant(int variant)
 {
-    if (variant < 0 || variant > 4095) return set_err(nullptr, PMP_E_INVALID, "pmp_debug_set_conv_variant: 0..5, or 10 + bits for the timing-only builds");
+#ifdef PMP_ABLATION
+    if (variant < 0 || variant > 4095) return set_err(nullptr, PMP_E_INVALID, "pmp_debug_set_conv_variant: 0..9, or 10 + bits for the timing-only builds");
+#else
+    // every variant the product library accepts computes bit-identical results; the timing-only builds (>= 10, wrong
+    // results) exist only in libpmp_hip_abl.so (make abl)
+    if (variant < 0 || variant > 9) return set_err(nullptr, PMP_E_INVALID, "pmp_debug_set_conv_variant: 0..9 (timing-only builds are not part of this library)");
+#endif
     g_conv_variant = variant;
     return PMP_OK;
-}
-
-int64_t pmp_debug_pack_f16x3(const float *w, int cout, int cin, int k, uint16_t *out, int64_t cap, int *scale_exp)
-{
-    if (!w || cout <= 0 || cin <= 0 || (k != 1 && k != 3 && k != 5) || !scale_exp)
-        return set_err(nullptr, PMP_E_INVALID, "pmp_debug_pack_f16x3: bad arguments");
-    const int kexp = h2_scale_exp(w, (size_t)cout * cin * k * k);
-    *scale_exp = kexp;
-    const std::vector<unsigned short> v = pack_h2(w, cout, cin, k, k, (cout + 15) & ~15, (cin + 15) & ~15, kexp);
-    if (out && (int64_t)v.size() <= cap) memcpy(out, v.data(), v.size() * sizeof(unsigned short));
-    return (int64_t)v.size();
 }
 
 int pmp_debug_conv_bench(pmp_ctx *c, int n, int h, int w, int cin, int cout, int k, int iters, double *ms_f32, double *ms_x6,
@@ -570,6 +472,7 @@ int pmp_debug_conv_bench(pmp_ctx *c, int n, int h, int w, int cin, int cout, int
         for (int i = 0; i < iters; ++i) launch_split();
         hipEventRecord(e1, c->stream); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
         if (ms_x6) *ms_x6 = ms / iters;
+#ifdef PMP_ABLATION
         if (!h2 && g_conv_variant == 10 + 128 && k == 3 && cout == 64) {   // in-kernel stamp report (diagnostic build)
             const int wgs = n * (h / 16) * (w / 16);
             unsigned long long *ddbg = nullptr;
@@ -621,6 +524,7 @@ int pmp_debug_conv_bench(pmp_ctx *c, int n, int h, int w, int cin, int cout, int
                 hipFree(ddbg);
             }
         }
+#endif
         if (h2) launch_split2_to_f32(c->stream, dys, dy2, ny, ny);
         else launch_split3_to_f32(c->stream, dys, dy2, ny, ny);
         std::vector<float> y1(ny), y2(ny);
@@ -638,67 +542,6 @@ int pmp_debug_conv_bench(pmp_ctx *c, int n, int h, int w, int cin, int cout, int
     }
     for (void *p : {(void *)dx, (void *)dy, (void *)dy2, (void *)dwp, (void *)dxs, (void *)dys, (void *)dwx}) if (p) hipFree(p);
     return rc;
-}
-
-int pmp_write_partition_binary(const char *path, int frames, int H, int W, const uint8_t *hor, const uint8_t *ver,
-                               const uint8_t *qt_u8, const int8_t *dire)
-{
-    if (!path || frames < 0 || H < 0 || W < 0 || !hor || !ver || !qt_u8 || !dire)
-        return set_err(nullptr, PMP_E_INVALID, "pmp_write_partition_binary: bad arguments");
-    const int bh = H / 64, bw = W / 64, R = 16 * bh, C = 16 * bw;
-    FILE *fp = fopen(path, "wb");
-    if (!fp) return set_err(nullptr, PMP_E_IO, std::string("cannot open ") + path);
-    const char magic[8] = {'P', 'M', 'P', 'B', '1', 0, 0, 0};
-    const int32_t hdr[8] = {frames, H, W, R, C, 0, 0, 0};
-    bool ok = fwrite(magic, 1, 8, fp) == 8 && fwrite(hdr, 4, 8, fp) == 8;
-    std::vector<uint8_t> row((size_t)(C > 0 ? C : 1));
-    for (int f = 0; f < frames && ok; ++f) {
-        const int64_t base = (int64_t)f * bh * bw;
-        for (int plane = 0; plane < 2 && ok; ++plane) {
-            const uint8_t *src = plane ? ver : hor;
-            for (int r = 0; r < R && ok; ++r) {
-                for (int cc = 0; cc < C; ++cc) row[cc] = src[(base + (r >> 4) * bw + (cc >> 4)) * 256 + (r & 15) * 16 + (cc & 15)];
-                ok = fwrite(row.data(), 1, (size_t)C, fp) == (size_t)C;
-            }
-        }
-        for (int r = 0; r < R / 2 && ok; ++r) {
-            for (int cc = 0; cc < C / 2; ++cc) row[cc] = qt_u8[(base + (r >> 3) * bw + (cc >> 3)) * 64 + (r & 7) * 8 + (cc & 7)];
-            ok = fwrite(row.data(), 1, (size_t)(C / 2), fp) == (size_t)(C / 2);
-        }
-        for (int k = 0; k < 3 && ok; ++k)
-            for (int r = 0; r < R && ok; ++r) {
-                for (int cc = 0; cc < C; ++cc)
-                    row[cc] = (uint8_t)dire[(base + (r >> 4) * bw + (cc >> 4)) * 768 + k * 256 + (r & 15) * 16 + (cc & 15)];
-                ok = fwrite(row.data(), 1, (size_t)C, fp) == (size_t)C;
-            }
-    }
-    const int cl = fclose(fp);
-    if (!ok || cl != 0) return set_err(nullptr, PMP_E_IO, std::string("short write to ") + path);
-    return PMP_OK;
-}
-
-int pmp_tile_partition_maps(int frames, int H, int W, const uint8_t *hor, const uint8_t *ver, const uint8_t *qt_u8,
-                            const int8_t *dire, uint8_t *out_hor, uint8_t *out_ver, uint8_t *out_qt, int8_t *out_dire)
-{
-    if (frames < 0 || H < 0 || W < 0 || !hor || !ver || !qt_u8 || !dire || !out_hor || !out_ver || !out_qt || !out_dire)
-        return set_err(nullptr, PMP_E_INVALID, "pmp_tile_partition_maps: bad arguments");
-    const int bh = H / 64, bw = W / 64, R = 16 * bh, C = 16 * bw;
-    for (int f = 0; f < frames; ++f) {
-        const int64_t base = (int64_t)f * bh * bw;
-        for (int r = 0; r < R; ++r)
-            for (int cc = 0; cc < C; ++cc) {
-                const int64_t blk = base + (r >> 4) * bw + (cc >> 4);
-                const int cell = (r & 15) * 16 + (cc & 15);
-                const int64_t o = ((int64_t)f * R + r) * C + cc;
-                out_hor[o] = hor[blk * 256 + cell];
-                out_ver[o] = ver[blk * 256 + cell];
-                for (int k = 0; k < 3; ++k) out_dire[(((int64_t)f * 3 + k) * R + r) * C + cc] = dire[blk * 768 + k * 256 + cell];
-            }
-        for (int r = 0; r < R / 2; ++r)
-            for (int cc = 0; cc < C / 2; ++cc)
-                out_qt[((int64_t)f * (R / 2) + r) * (C / 2) + cc] = qt_u8[(base + (r >> 3) * bw + (cc >> 3)) * 64 + (r & 7) * 8 + (cc & 7)];
-    }
-    return PMP_OK;
 }
 
 // ---- timing ------------------------------------------------------------------------------------------------

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/pmp.h"
+#include "pmp_hostonly.h"
 #include "pmp_kernels.h"
 
 namespace pmp {
@@ -83,11 +84,6 @@ int hip_fail(pmp_ctx *c, hipError_t e, const char *what);
 // weights_pack.cpp
 int load_net_weights(pmp_ctx *c, int net_id, int qp, const float *blob, const pmp_tensor_desc *descs, int ndesc);
 void free_net_weights(NetWeights &w);
-std::vector<float> pack_mfma(const float *w, int cout, int cin, int kh, int kw, int cout_pad, int cin_pad);
-std::vector<unsigned short> pack_x6(const float *w, int cout, int cin, int kh, int kw, int cout_pad, int cin_pad);
-std::vector<unsigned short> pack_h2(const float *w, int cout, int cin, int kh, int kw, int cout_pad, int cin_pad, int scale_exp);
-int h2_scale_exp(const float *w, size_t n);
-std::vector<unsigned short> pack_stem_h2(const float *w32, int cin, int k1, int scale_exp);
 
 // nets.cpp: forward graphs on device pointers (n <= chunk); all launches go to c->stream.
 int forward_q(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, const uint8_t *bu, const uint8_t *bv,

@@ -1,0 +1,25 @@
+// Declarations shared by the host-only translation units (host_emit.cpp, pack.cpp) and the rest of the library.
+// Nothing here needs the HIP runtime: these files also build into the CPU-only sanitizer test library (make hostasan).
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/pmp.h"
+
+namespace pmp {
+
+// the calling thread's context-less error string (pmp_last_error(NULL)); returns `code`
+int set_err_global(int code, const std::string &msg);
+const char *global_err();
+
+// pack.cpp: OIHW fp32 weights -> fragment-order streams
+std::vector<float> pack_mfma(const float *w, int cout, int cin, int kh, int kw, int cout_pad, int cin_pad);
+std::vector<unsigned short> pack_x6(const float *w, int cout, int cin, int kh, int kw, int cout_pad, int cin_pad);
+std::vector<unsigned short> pack_h2(const float *w, int cout, int cin, int kh, int kw, int cout_pad, int cin_pad, int scale_exp);
+int h2_scale_exp(const float *w, size_t n);
+std::vector<unsigned short> pack_stem_h2(const float *w32, int cin, int k1, int scale_exp);
+std::vector<float> pack_plain(const float *w, int cout, int cin, int kh, int kw);
+
+}  // namespace pmp

@@ -55,180 +55,9 @@ struct Uploader {
     }
 };
 
-// OIHW conv weight -> MFMA A-operand fragments [Cin_pad/16][KH*KW][Cout_pad/16][64 lanes][4]:
-// lane l of cout-tile nt holds W[cout = 16nt + (l&15)][channel = 16cb + 4(l>>4) + j], j = 0..3 (conv_mfma.hip).
-}  // namespace
-std::vector<float> pack_mfma(const float *w, int cout, int cin, int kh, int kw, int cout_pad, int cin_pad)
-{
-    const int taps = kh * kw, CB = cin_pad / 16, NT = cout_pad / 16;
-    std::vector<float> out((size_t)CB * taps * NT * 64 * 4, 0.f);
-    for (int cb = 0; cb < CB; ++cb)
-        for (int t = 0; t < taps; ++t)
-            for (int nt = 0; nt < NT; ++nt)
-                for (int l = 0; l < 64; ++l)
-                    for (int j = 0; j < 4; ++j) {
-                        const int co = nt * 16 + (l & 15), ci = cb * 16 + 4 * (l >> 4) + j;
-                        float v = 0.f;
-                        if (co < cout && ci < cin) v = w[((size_t)co * cin + ci) * taps + t];
-                        out[((((size_t)cb * taps + t) * NT + nt) * 64 + l) * 4 + j] = v;
-                    }
-    return out;
-}
-namespace {
-
 }  // namespace
 
-// fp32 -> bf16, round to nearest even (weights are finite)
-static inline unsigned short bf16_rne(float f)
-{
-    unsigned u;
-    std::memcpy(&u, &f, 4);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-static inline float bf16_f32(unsigned short h)
-{
-    unsigned u = (unsigned)h << 16;
-    float f;
-    std::memcpy(&f, &u, 4);
-    return f;
-}
-
-// OIHW conv weight -> split-3 bf16 MFMA A-operand fragments (conv_bf16x6.hip), one K-step = 16 channels x 2 taps:
-// [K-step][3 splits][Cout_pad/16][64 lanes][8]; lane l of cout-tile nt holds W[cout = 16nt + (l&15)][channel = 16cb +
-// 8((l>>4)&1) + j][tap], where (cb, tap) of the lane's half (l>>5) follows the kernel's K-step order:
-//   plain  (odd number of channel groups, or even tap count): per group ceil(T/2) K-steps (2ks, 2ks+1), zero beyond T;
-//   paired (even number of groups, odd T): group 2p: (T-1)/2 K-steps (2ks, 2ks+1); group 2p+1: the same, then one K-step
-//          pairing tap T-1 of group 2p (lanes l<32) with tap T-1 of group 2p+1 (lanes l>=32).
-std::vector<unsigned short> pack_x6(const float *w, int cout, int cin, int kh, int kw, int cout_pad, int cin_pad)
-{
-    const int taps = kh * kw, CB = cin_pad / 16, NT = cout_pad / 16;
-    const bool paired = (CB % 2 == 0) && (taps % 2 == 1);
-    struct Half { int cb, tap; };
-    std::vector<std::pair<Half, Half>> steps;
-    if (paired) {
-        for (int cb = 0; cb < CB; ++cb) {   // the cross-group pair is the FIRST K-step of the odd group
-            if (cb & 1) steps.push_back({{cb - 1, taps - 1}, {cb, taps - 1}});
-            for (int ks = 0; ks < (taps - 1) / 2; ++ks) steps.push_back({{cb, 2 * ks}, {cb, 2 * ks + 1}});
-        }
-    } else {
-        for (int cb = 0; cb < CB; ++cb)
-            for (int ks = 0; ks < (taps + 1) / 2; ++ks) steps.push_back({{cb, 2 * ks}, {cb, 2 * ks + 1}});   // tap >= T -> zeros
-    }
-    std::vector<unsigned short> out(steps.size() * 3 * NT * 64 * 8, 0);
-    for (size_t st = 0; st < steps.size(); ++st)
-        for (int nt = 0; nt < NT; ++nt)
-            for (int l = 0; l < 64; ++l)
-                for (int j = 0; j < 8; ++j) {
-                    const int g = l >> 4;
-                    const Half h = (g >> 1) ? steps[st].second : steps[st].first;
-                    const int co = nt * 16 + (l & 15), ci = h.cb * 16 + 8 * (g & 1) + j, t = h.tap;
-                    float v = 0.f;
-                    if (co < cout && ci < cin && t < taps) v = w[((size_t)co * cin + ci) * taps + t];
-                    const unsigned short h0 = bf16_rne(v);
-                    const float r1 = v - bf16_f32(h0);
-                    const unsigned short h1 = bf16_rne(r1);
-                    const float r2 = r1 - bf16_f32(h1);
-                    const unsigned short h2 = bf16_rne(r2);
-                    const unsigned short hs[3] = {h0, h1, h2};
-                    for (int sp = 0; sp < 3; ++sp) out[(((st * 3 + sp) * NT + nt) * 64 + l) * 8 + j] = hs[sp];
-                }
-    return out;
-}
-
-// Power-of-two scale for the fp16 split (conv_f16x3.hip): S = 2^k with max|S*w| in [4096, 8192); k in [0, 24].
-int h2_scale_exp(const float *w, size_t n)
-{
-    float m = 0.f;
-    for (size_t i = 0; i < n; ++i) m = std::fmax(m, std::fabs(w[i]));
-    if (!(m > 0.f) || !std::isfinite(m)) return 0;
-    int e = 0;
-    std::frexp(m, &e);            // m = f * 2^e, f in [0.5, 1)
-    int k = 13 - e;               // S*m = f * 2^13 in [4096, 8192)
-    return k < 0 ? 0 : (k > 24 ? 24 : k);
-}
-
-// Same K-step stream as pack_x6, two fp16 terms of S*w per element: [step][2 splits][cout_pad/16][64 lanes][8].
-std::vector<unsigned short> pack_h2(const float *w, int cout, int cin, int kh, int kw, int cout_pad, int cin_pad, int scale_exp)
-{
-    const int taps = kh * kw, CB = cin_pad / 16, NT = cout_pad / 16;
-    const bool paired = (CB % 2 == 0) && (taps % 2 == 1);
-    const float S = std::ldexp(1.f, scale_exp);
-    struct Half { int cb, tap; };
-    std::vector<std::pair<Half, Half>> steps;
-    if (paired) {
-        for (int cb = 0; cb < CB; ++cb) {
-            if (cb & 1) steps.push_back({{cb - 1, taps - 1}, {cb, taps - 1}});
-            for (int ks = 0; ks < (taps - 1) / 2; ++ks) steps.push_back({{cb, 2 * ks}, {cb, 2 * ks + 1}});
-        }
-    } else {
-        for (int cb = 0; cb < CB; ++cb)
-            for (int ks = 0; ks < (taps + 1) / 2; ++ks) steps.push_back({{cb, 2 * ks}, {cb, 2 * ks + 1}});
-    }
-    auto bits = [](_Float16 h) { unsigned short u; std::memcpy(&u, &h, 2); return u; };
-    std::vector<unsigned short> out(steps.size() * 2 * NT * 64 * 8, 0);
-    for (size_t st = 0; st < steps.size(); ++st)
-        for (int nt = 0; nt < NT; ++nt)
-            for (int l = 0; l < 64; ++l)
-                for (int j = 0; j < 8; ++j) {
-                    const int g = l >> 4;
-                    const Half h = (g >> 1) ? steps[st].second : steps[st].first;
-                    const int co = nt * 16 + (l & 15), ci = h.cb * 16 + 8 * (g & 1) + j, t = h.tap;
-                    float v = 0.f;
-                    if (co < cout && ci < cin && t < taps) v = w[((size_t)co * cin + ci) * taps + t] * S;
-                    const _Float16 h0 = (_Float16)v;
-                    const _Float16 h1 = (_Float16)(v - (float)h0);
-                    out[(((st * 2 + 0) * NT + nt) * 64 + l) * 8 + j] = bits(h0);
-                    out[(((st * 2 + 1) * NT + nt) * 64 + l) * 8 + j] = bits(h1);
-                }
-    return out;
-}
-
-// Stem weights for the MFMA stem (conv_misc.hip: stem_mfma_kernel): ONE k1 x k1 convolution with 32 outputs, top-left
-// anchored (the smaller kernels of the MTT stems are zero-padded into it).  w32: [32][cin][k1][k1].  K is ordered
-// (dy, ci, dx) with dx padded to DXW = 16 (k1 > 8) or 8 slots and ci padded so that it divides 32/DXW; a K-step of 32 covers
-// 32/DXW (dy, ci) rows.
-// Stream: [K-step][2 splits][2 cout groups][64 lanes][8] fp16 terms of 2^scale_exp * w.
-std::vector<unsigned short> pack_stem_h2(const float *w32, int cin, int k1, int scale_exp)
-{
-    const int DXW = k1 > 8 ? 16 : 8, RPK = 32 / DXW;
-    const int cinp = (RPK % cin == 0) ? cin : 4;   // chroma QT: 3 planes padded to 4 so a lane's input row advances uniformly
-    const int NROW = k1 * cinp, KS = (NROW + RPK - 1) / RPK;
-    const float S = std::ldexp(1.f, scale_exp);
-    auto bits = [](_Float16 h) { unsigned short u; std::memcpy(&u, &h, 2); return u; };
-    std::vector<unsigned short> out((size_t)KS * 2 * 2 * 64 * 8, 0);
-    for (int ks = 0; ks < KS; ++ks)
-        for (int nt = 0; nt < 2; ++nt)
-            for (int l = 0; l < 64; ++l)
-                for (int j = 0; j < 8; ++j) {
-                    const int g = l >> 4, co = nt * 16 + (l & 15);
-                    const int kr = DXW == 16 ? RPK * ks + (g >> 1) : RPK * ks + g;
-                    const int dx = (DXW == 16 ? 8 * (g & 1) : 0) + j;
-                    float v = 0.f;
-                    if (kr < NROW && dx < k1) {
-                        const int dy = kr / cinp, ci = kr % cinp;
-                        if (ci < cin) v = w32[(((size_t)co * cin + ci) * k1 + dy) * k1 + dx] * S;
-                    }
-                    const _Float16 h0 = (_Float16)v;
-                    const _Float16 h1 = (_Float16)(v - (float)h0);
-                    out[((((size_t)ks * 2 + 0) * 2 + nt) * 64 + l) * 8 + j] = bits(h0);
-                    out[((((size_t)ks * 2 + 1) * 2 + nt) * 64 + l) * 8 + j] = bits(h1);
-                }
-    return out;
-}
-
 namespace {
-
-// OIHW -> [tap][cin][cout] (direct kernels, stems, heads)
-std::vector<float> pack_plain(const float *w, int cout, int cin, int kh, int kw)
-{
-    const int taps = kh * kw;
-    std::vector<float> out((size_t)taps * cin * cout);
-    for (int t = 0; t < taps; ++t)
-        for (int ci = 0; ci < cin; ++ci)
-            for (int co = 0; co < cout; ++co) out[((size_t)t * cin + ci) * cout + co] = w[((size_t)co * cin + ci) * taps + t];
-    return out;
-}
 
 int need(pmp_ctx *c, const Blob &b, const std::string &name, std::initializer_list<int> shape, const float **out)
 {

@@ -31,8 +31,11 @@ def _u8(a):
 
 
 class Engine:
-    def __init__(self, device=0, weight_dir=None, chunk=None):
+    def __init__(self, device=0, weight_dir=None, chunk=None, allow_synthetic_mtt=False):
+        """allow_synthetic_mtt: let load() fall back to the synthetic MTT-net weights when a *_BD_* file is missing (tests,
+        bench, smoke); off by default - a production run with a missing model file must fail (Inference_QBD.py:219-222)."""
         self.lib = _lib.load()
+        self.allow_synthetic_mtt = bool(allow_synthetic_mtt)
         self.h = C.c_void_p()
         _lib.check(self.lib.pmp_create(int(device), C.byref(self.h)))
         self.device = device
@@ -104,7 +107,7 @@ class Engine:
             if given is None:
                 if self.has_weights(net, qp):
                     continue
-                given, src = W.load_net_weights(net, qp, self.weight_dir)
+                given, src = W.load_net_weights(net, qp, self.weight_dir, allow_synthetic=self.allow_synthetic_mtt)
             else:
                 src = "caller"
             self.load_pretrain_model(net, qp, given)
@@ -266,8 +269,8 @@ def format_partition_text(frames, height, width, hor, ver, qt_u8, dire_i8):
     hor = np.ascontiguousarray(hor, np.uint8); ver = np.ascontiguousarray(ver, np.uint8)
     q8 = np.ascontiguousarray(qt_u8, np.uint8); d8 = np.ascontiguousarray(dire_i8, np.int8)
     need = _lib.check(lib.pmp_format_partition_text(int(frames), int(height), int(width), _ptr(hor), _ptr(ver), _ptr(q8), _ptr(d8), None, 0))
-    buf = C.create_string_buffer(int(need) + 96)      # the formatter wants room for one more row while it writes
-    got = _lib.check(lib.pmp_format_partition_text(int(frames), int(height), int(width), _ptr(hor), _ptr(ver), _ptr(q8), _ptr(d8), buf, need + 96))
+    buf = C.create_string_buffer(max(int(need), 1))
+    got = _lib.check(lib.pmp_format_partition_text(int(frames), int(height), int(width), _ptr(hor), _ptr(ver), _ptr(q8), _ptr(d8), buf, need))
     assert got == need
     return buf.raw[:need]
 

@@ -33,6 +33,8 @@ from . import engine as E
 from . import parallel
 
 QPS = (22, 27, 32, 37)
+COMP_COLUMN = {"Luma": 0, "Chroma": 1}
+DEFAULT_MODEL_DIR = "./CTU_Models"                 # Inference_QBD.py:219-220
 
 
 def load_sequences_info(seqs_info_path, ss_ratio, num=None):
@@ -104,7 +106,7 @@ def build_parser():
     # paths the reference hard-codes
     p.add_argument("--seqTable", default="VVC_Test_Sequences.txt")
     p.add_argument("--cfgDir", default=os.path.join(".", "per-sequence"))
-    p.add_argument("--modelDir", default="./CTU_Models")
+    p.add_argument("--modelDir", default=DEFAULT_MODEL_DIR)
     p.add_argument("--ssRatio", default=30, type=int, help="temporal sub-sampling (Inference_QBD.py:26)")
     p.add_argument("--qps", default="22,27,32,37")
     p.add_argument("--comps", default="Luma,Chroma")
@@ -112,6 +114,9 @@ def build_parser():
     p.add_argument("--binary", action="store_true", help="also write <name>_PartitionMat.pmpb (binary side channel, include/pmp.h)")
     p.add_argument("--strictBatch", action="store_true",
                    help="run exactly --batchSize blocks per pass (default: the library's 4096-block chunk; same results)")
+    p.add_argument("--allowSyntheticMTT", action="store_true",
+                   help="run the MTT nets on the documented SYNTHETIC weights when a <Comp>_BD_<qp> model file is missing (the "
+                        "reference checkout ships none); without this flag a missing model file is an error, as in the reference")
     p.add_argument("--hostBlocks", action="store_true",
                    help="keep the cut blocks in host memory and upload them for every (component, QP) pass, as the reference "
                         "does; default: frames are uploaded once, cut on the GPU and the blocks stay device-resident")
@@ -163,6 +168,16 @@ def _emit(rec, save_path, frames, height, width, binary):
         E.write_partition_binary(save_path[:-4] + ".pmpb", frames, height, width, h, v, q, d)
 
 
+def resolve_model_dir(model_dir):
+    """--modelDir as given must exist; only the untouched default (./CTU_Models, Inference_QBD.py:219-220) falls back to
+    the packaged weights/ directory when it is absent.  A mistyped directory is an error, not a silent fallback."""
+    if os.path.isdir(model_dir):
+        return model_dir
+    if model_dir == DEFAULT_MODEL_DIR:
+        return None                                   # weights.default_weight_dir()
+    raise FileNotFoundError("--modelDir %s does not exist" % model_dir)
+
+
 def _resolve(path, base):
     return path if os.path.isabs(path) or os.path.exists(path) else os.path.join(base, path)
 
@@ -174,10 +189,12 @@ def inference_VVC_seqs(args):
     if args.device is None and world > 1:
         import torch
         dev_id = local % max(torch.cuda.device_count(), 1)   # several ranks may share a GPU in smoke tests (gloo)
-    eng = E.Engine(dev_id, weight_dir=args.modelDir if os.path.isdir(args.modelDir) else None)
+    model_dir = resolve_model_dir(args.modelDir)
+    eng = E.Engine(dev_id, weight_dir=model_dir, allow_synthetic_mtt=args.allowSyntheticMTT)
     # --batchSize is the reference's blocks-per-forward-pass (a GPU memory knob there).  Results do not depend on it (tested:
-    # ragged chunks are bit-identical to one pass); small passes only leave most of an MI355X idle, so it is ignored unless --strictBatch asks for it
-    eng.set_chunk(max(1, args.batchSize) if args.strictBatch else 4096)
+    # ragged chunks are bit-identical to one pass); small passes only leave most of an MI355X idle, so it is ignored unless
+    # --strictBatch asks for it (clamped to the library's 4096-block pass; the reference accepts any value)
+    eng.set_chunk(min(max(1, args.batchSize), 4096) if args.strictBatch else 4096)
     device = None
     if world > 1:
         import torch
@@ -209,9 +226,15 @@ def inference_VVC_seqs(args):
 
     writers = ThreadPoolExecutor(max_workers=4) if rank == 0 else None
     pending = []
-    for comp in comps:  # weights once per (comp, qp), not once per sequence
+    for comp in comps:  # weights once per (comp, qp), not once per sequence; a missing file raises here, before any output
         for qp in qps:
             eng.load(comp, qp)
+    if rank == 0:
+        for (net, qp), src in sorted(eng.provenance.items()):
+            print("weights %s QP%d: %s" % (net, qp, src), flush=True)
+        if any(str(src).startswith("synthetic") for src in eng.provenance.values()):
+            print("WARNING: MTT nets run on SYNTHETIC weights (--allowSyntheticMTT): the PartitionMat files are not usable "
+                  "for encoding", file=sys.stderr, flush=True)
 
     for si, seq_id in enumerate(range(args.startSeqID, end)):
         seq_name, stem = names[seq_id], strip_yuv_suffix(files[seq_id])
@@ -240,7 +263,8 @@ def inference_VVC_seqs(args):
             by = np.zeros((0, 68, 68), np.uint8); bu = np.zeros((0, 34, 34), np.uint8); bv = np.zeros((0, 34, 34), np.uint8)
         seqs_block_time[si] = time.time() - t0
 
-        for comp_id, comp in enumerate(comps):
+        for comp in comps:
+            comp_id = COMP_COLUMN[comp]                # Time_Sta columns: Luma first, whatever --comps lists
             for qp in qps:
                 qi = (qp - 22) // 5 if qp in QPS else 0
                 t0 = time.time()

@@ -55,7 +55,7 @@ def load_pkl(path):
     """Reference pickle -> {name: float32 ndarray}; mirrors remove_prefix/load_pretrain_model
     (Inference_QBD.py:28-46) but with map_location='cpu' (the shipped loader fails on CPU-only hosts)."""
     import torch
-    sd = torch.load(path, map_location="cpu", weights_only=False)
+    sd = torch.load(path, map_location="cpu", weights_only=True)   # plain state_dicts: no pickle code is executed
     if "state_dict" in sd:
         sd = sd["state_dict"]
     return {(k.split("module.", 1)[-1] if k.startswith("module.") else k):
@@ -73,10 +73,12 @@ def ref_net_name(net):
     return comp + ("_Q" if kind == "Q" else "_BD")
 
 
-def load_net_weights(net, qp, weight_dir=None, allow_synthetic=True):
-    """Resolution order: <dir>/<Comp>_{Q,BD}_<qp>.pmpw, then .pkl (reference naming, Inference_QBD.py:219-220),
-    then - for the MTT nets only, whose files are absent from the reference mount - the documented
-    synthetic generator (seed = qp).  Returns (weights, provenance-string)."""
+def load_net_weights(net, qp, weight_dir=None, allow_synthetic=False):
+    """Resolution order: <dir>/<Comp>_{Q,BD}_<qp>.pmpw, then .pkl (reference naming, Inference_QBD.py:219-220).  A missing
+    file is an error, as in the reference (Inference_QBD.py:219-222 dies on a missing model file) - unless
+    allow_synthetic=True, which for the MTT nets only (their files are absent from the reference mount)
+    falls back to the documented synthetic generator (seed = qp): tests, bench.py and smoke() ask for it explicitly, the
+    CLI driver only with --allowSyntheticMTT.  Returns (weights, provenance-string)."""
     d = weight_dir or default_weight_dir()
     stem = "%s_%d" % (ref_net_name(net), qp)
     p = os.path.join(d, stem + ".pmpw")
@@ -88,4 +90,6 @@ def load_net_weights(net, qp, weight_dir=None, allow_synthetic=True):
     if net.endswith("_MSBD") and allow_synthetic:
         from . import synth
         return synth.synth_msbd_weights(net.split("_")[0], qp), "synthetic(seed=%d)" % qp
-    raise FileNotFoundError("no weights for %s qp%d under %s" % (net, qp, d))
+    hint = " (MTT-net files are not part of the reference checkout; --allowSyntheticMTT / allow_synthetic=True runs on " \
+           "documented synthetic weights instead)" if net.endswith("_MSBD") else ""
+    raise FileNotFoundError("no weights for %s qp%d: neither %s.pmpw nor %s.pkl under %s%s" % (net, qp, stem, stem, d, hint))

@@ -1,0 +1,110 @@
+"""Run by tests/test_hostasan_cpu.py in a child process with the ASan runtime preloaded: drives every host-only entry point
+of the C ABI (text / binary emission, frame tiling, f16x3 weight packing) in the sanitizer build libpmp_hostasan.so
+(make -C pmp_vvc_tip2023_amd/csrc hostasan).  Any AddressSanitizer / UBSan report aborts the process (non-zero exit)."""
+import ctypes as C
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from pmp_vvc_tip2023_amd import _lib  # noqa: E402
+
+_lib._lib = _lib.open_library(_lib.HOSTASAN_LIB_PATH, subset=True)   # before engine's helpers call _lib.load()
+from pmp_vvc_tip2023_amd import engine  # noqa: E402
+
+lib = _lib.load()
+assert b"hostasan" in lib.pmp_version()
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def blocks_from_text(path, F, H, W):
+    ph, pv, pq, pd = engine.read_partition_file(path, F, H, W)
+    bh, bw = H // 64, W // 64
+
+    def tb(m, s):
+        return m.reshape(F, bh, s, bw, s).transpose(0, 1, 3, 2, 4).reshape(F * bh * bw, s, s)
+    d8 = np.stack([tb(pd[:, k], 16) for k in range(3)], 1).astype(np.int8)
+    return tb(ph, 16).astype(np.uint8), tb(pv, 16).astype(np.uint8), tb(pq, 8).astype(np.uint8), d8
+
+
+def main():
+    tmp = tempfile.mkdtemp()
+    # 1. golden text files (reference output) -> per-block arrays -> product writer: same bytes, via both entry points
+    for comp in ("Luma", "Chroma"):
+        g = np.load(os.path.join(GOLD, "g5_seq_%s.npz" % comp))
+        F, W, H = int(g["F"]), int(g["W"]), int(g["H"])
+        src = os.path.join(GOLD, "g5_partitionmat_%s.txt" % comp)
+        hor, ver, q8, d8 = blocks_from_text(src, F, H, W)
+        ref = open(src, "rb").read()
+        assert engine.format_partition_text(F, H, W, hor, ver, q8, d8) == ref
+        p = os.path.join(tmp, comp + ".txt")
+        engine.write_partition_file(p, F, H, W, hor, ver, q8, d8)
+        assert open(p, "rb").read() == ref
+        pb = os.path.join(tmp, comp + ".pmpb")
+        engine.write_partition_binary(pb, F, H, W, hor, ver, q8, d8)
+        f, h, w, bh, bv, bq, bd = engine.read_partition_binary(pb)
+        th, tv, tq, td = engine.read_partition_file(src, F, H, W)
+        assert np.array_equal(bh, th) and np.array_equal(bv, tv) and np.array_equal(bq, tq) and np.array_equal(bd, td)
+        mh, mv, mq, md = engine.tile_partition_maps(F, H, W, hor, ver, q8, d8)
+        assert np.array_equal(mh, th) and np.array_equal(md, td) and np.array_equal(mq, tq)
+    # 2. the reference's real demo frame (non-multiple-of-64 geometry: 416x240)
+    src = os.path.join(GOLD, "g7_racehorses_luma_qp22_frame0.txt")
+    hor, ver, q8, d8 = blocks_from_text(src, 1, 240, 416)
+    assert engine.format_partition_text(1, 240, 416, hor, ver, q8, d8) == open(src, "rb").read()
+    # 3. arbitrary caller data: multi-digit and negative values take the slow formatter paths; exact-size contract
+    rng = np.random.default_rng(3)
+    for F, H, W in ((1, 64, 64), (2, 136, 200), (3, 64, 320), (0, 64, 64), (1, 63, 640)):
+        n = F * (H // 64) * (W // 64)
+        hor = rng.integers(0, 256, (n, 16, 16)).astype(np.uint8); ver = rng.integers(0, 2, (n, 16, 16)).astype(np.uint8)
+        q8 = rng.integers(0, 256, (n, 8, 8)).astype(np.uint8); d8 = rng.integers(-128, 128, (n, 3, 16, 16)).astype(np.int8)
+        text = engine.format_partition_text(F, H, W, hor, ver, q8, d8)
+        vals = np.array(text.split(), dtype=np.int64)
+        R, Cc = (H >> 6) * 16, (W >> 6) * 16
+        assert vals.size == F * (5 * R * Cc + R * Cc // 4)
+        if n:
+            mh, mv, mq, md = engine.tile_partition_maps(F, H, W, hor, ver, q8, d8)
+            per = 5 * R * Cc + R * Cc // 4
+            v = vals.reshape(F, per)
+            assert np.array_equal(v[:, :R * Cc].reshape(F, R, Cc), mh)
+            assert np.array_equal(v[:, 2 * R * Cc + R * Cc // 4:].reshape(F, 3, R, Cc), md)
+        # an exactly-sized buffer is filled exactly; a smaller one is refused, never overrun
+        need = lib.pmp_format_partition_text(F, H, W, hor.ctypes.data, ver.ctypes.data, q8.ctypes.data, d8.ctypes.data, None, 0)
+        assert need == len(text)
+        buf = C.create_string_buffer(max(int(need), 1))
+        got = lib.pmp_format_partition_text(F, H, W, hor.ctypes.data, ver.ctypes.data, q8.ctypes.data, d8.ctypes.data, buf, need)
+        assert got == need and buf.raw[:need] == text
+        small = C.create_string_buffer(max(int(need) // 2, 1))
+        if n:
+            assert lib.pmp_format_partition_text(F, H, W, hor.ctypes.data, ver.ctypes.data, q8.ctypes.data, d8.ctypes.data, small,
+                                                 max(int(need) // 2, 1)) == -1
+    # 4. error paths
+    assert lib.pmp_tile_partition_maps(1, 64, 64, None, None, None, None, None, None, None, None) == -1
+    assert lib.pmp_write_partition_file(None, 1, 64, 64, None, None, None, None) == -1
+    z = np.zeros((1, 16, 16), np.uint8)
+    assert lib.pmp_write_partition_binary(os.path.join(tmp, "nodir", "x").encode(), 1, 64, 64, z.ctypes.data, z.ctypes.data,
+                                          np.zeros(64, np.uint8).ctypes.data, np.zeros(768, np.int8).ctypes.data) == -4
+    assert b"cannot open" in lib.pmp_last_error(None)
+    # 5. weight packing for every conv shape of the four nets (and odd shapes), both buffer modes
+    for cout, cin, k in ((64, 64, 3), (64, 32, 5), (64, 64, 5), (32, 64, 3), (32, 128, 3), (32, 32, 3), (16, 32, 3), (8, 16, 3),
+                         (32, 3, 3), (64, 32, 1), (32, 17, 5), (8, 32, 1), (1, 1, 1)):
+        w = (rng.standard_normal((cout, cin, k, k)) * 0.05).astype(np.float32)
+        kexp = C.c_int(-1)
+        wp = w.ctypes.data_as(C.POINTER(C.c_float))
+        n = lib.pmp_debug_pack_f16x3(wp, cout, cin, k, None, 0, C.byref(kexp))
+        assert n > 0 and 0 <= kexp.value <= 24
+        out = np.zeros(n, np.uint16)
+        assert lib.pmp_debug_pack_f16x3(wp, cout, cin, k, out.ctypes.data_as(C.POINTER(C.c_uint16)), n, C.byref(kexp)) == n
+        short = np.zeros(max(n - 1, 1), np.uint16)   # too small: nothing may be written
+        assert lib.pmp_debug_pack_f16x3(wp, cout, cin, k, short.ctypes.data_as(C.POINTER(C.c_uint16)), n - 1, C.byref(kexp)) == n
+        assert not short.any()
+    assert lib.pmp_debug_pack_f16x3(None, 1, 1, 1, None, 0, None) == -1
+    print("hostasan checks passed")
+
+
+if __name__ == "__main__":
+    main()

@@ -162,3 +162,15 @@ def test_f16x3_weight_packing_is_exact_to_22_bits(lib, cout, cin, k):
                         assert v == 0.0
     assert (seen == 1).all()
     assert worst <= 2.0 ** -21
+
+
+def test_product_library_has_no_ablation_knobs(lib):
+    """The timing-only kernel builds (wrong results) and the PMP_CONV_VARIANT environment knob exist only in the measurement
+    library libpmp_hip_abl.so (make abl).  The product library rejects their variant numbers and never reads the variable."""
+    assert lib.pmp_debug_set_conv_variant(3) == 0 and lib.pmp_debug_set_conv_variant(2) == 0
+    for bad in (10, 11, 18, 138, 1162, -1, 4096):
+        assert lib.pmp_debug_set_conv_variant(bad) == -1, bad
+    assert b"timing-only" in lib.pmp_last_error(None) or b"0..9" in lib.pmp_last_error(None)
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"PMP_CONV_VARIANT" not in blob
+    assert b"abl" not in lib.pmp_version()

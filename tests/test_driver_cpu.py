@@ -74,3 +74,31 @@ def test_tile_partition_maps_matches_the_text_layout_and_rejects_bad_arguments()
     lib = _lib.load()
     assert lib.pmp_tile_partition_maps(F, H, W, None, None, None, None, None, None, None, None) == -1
     assert b"pmp_tile_partition_maps" in lib.pmp_last_error(None)
+
+
+def test_missing_mtt_weights_are_an_error_unless_asked_for(tmp_path):
+    """Inference_QBD.py:219-222: the reference dies when a model file is missing.  The MTT-net files (*_BD_*) are absent from
+    the reference checkout, so the loader refuses them by default and only the explicit opt-in falls back to the documented
+    synthetic generator; a mistyped --modelDir is an error, not a silent fallback to the packaged weights."""
+    import pytest
+    from pmp_vvc_tip2023_amd import weights as W
+    assert D.build_parser().parse_args([]).allowSyntheticMTT is False
+    assert D.build_parser().parse_args(["--allowSyntheticMTT"]).allowSyntheticMTT is True
+    w, src = W.load_net_weights("Luma_Q", 22)                       # the QT nets are real files
+    assert src.endswith("Luma_Q_22.pmpw") and "conv_q1.weight" in w
+    with pytest.raises(FileNotFoundError) as e:
+        W.load_net_weights("Luma_MSBD", 22)
+    assert "Luma_BD_22" in str(e.value) and "allowSyntheticMTT" in str(e.value)
+    w, src = W.load_net_weights("Luma_MSBD", 22, allow_synthetic=True)
+    assert src == "synthetic(seed=22)" and len(w) == 72
+    with pytest.raises(FileNotFoundError):
+        W.load_net_weights("Luma_Q", 22, weight_dir=str(tmp_path), allow_synthetic=True)   # never synthetic QT weights
+    # --modelDir: the untouched default may be absent (packaged weights/ are used), an explicit one must exist
+    assert D.resolve_model_dir(D.DEFAULT_MODEL_DIR) in (None, D.DEFAULT_MODEL_DIR)
+    assert D.resolve_model_dir(str(tmp_path)) == str(tmp_path)
+    with pytest.raises(FileNotFoundError):
+        D.resolve_model_dir(str(tmp_path / "CTU_Modles"))
+
+
+def test_time_sta_columns_follow_the_component_not_the_flag_order():
+    assert D.COMP_COLUMN == {"Luma": 0, "Chroma": 1}

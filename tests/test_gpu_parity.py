@@ -14,7 +14,7 @@ TOL = 1e-3  # north_star: "within 1e-3 fp32 on the map logits"
 def eng(request):
     """Every parity test runs on all three convolution datapaths (fp16 2-term split, bf16 3-term split, exact fp32 MFMA)."""
     from pmp_vvc_tip2023_amd import engine
-    e = engine.Engine(0)
+    e = engine.Engine(0, allow_synthetic_mtt=True)
     e.set_precision(request.param)
     assert e.get_precision() == request.param
     yield e
@@ -63,7 +63,7 @@ def test_logits_vs_oracle_fresh_inputs_and_chunking(eng, comp):
     qp = 27
     qt, bt, dire = eng.inference_pre_QBD(comp, qp, y, u, v)
     wq, _ = W.load_net_weights(comp + "_Q", qp)
-    wbd, _ = W.load_net_weights(comp + "_MSBD", qp)
+    wbd, _ = W.load_net_weights(comp + "_MSBD", qp, allow_synthetic=True)
     x = O.luma_input(y) if luma else O.chroma_input(y, u, v)
     oq, obt, odire = O.infer_qbd(wq, wbd, x, luma)
     assert np.abs(qt - oq).max() < TOL and np.abs(bt - obt).max() < TOL and np.abs(dire - odire).max() < TOL
@@ -112,7 +112,7 @@ def test_default_chunk_boundary(eng):
 
 def test_caller_supplied_weights_and_errors(eng, g1):
     from pmp_vvc_tip2023_amd import _lib, engine, synth
-    e2 = engine.Engine(0)
+    e2 = engine.Engine(0, allow_synthetic_mtt=True)
     try:
         with pytest.raises(_lib.PmpError) as ei:           # nothing loaded yet
             e2._ck(e2.lib.pmp_infer(e2.h, 0, 22, None, None, None, 1, None, None, None))
@@ -142,7 +142,7 @@ def test_f16x3_saturates_instead_of_overflowing(g1):
     """f16x3 carries activations as two fp16 terms: values beyond +-65504 must saturate when split, never turn into inf/NaN
     (include/pmp.h, PMP_PRECISION_F16X3).  A stem scaled by 1e3 drives the trunk far beyond that range."""
     from pmp_vvc_tip2023_amd import engine, synth
-    e2 = engine.Engine(0)
+    e2 = engine.Engine(0, allow_synthetic_mtt=True)
     try:
         e2.set_precision("f16x3")
         e2.load("Luma", 22)                                 # real QT net for the MTT net's second input
@@ -165,7 +165,7 @@ def test_f16x3_conv_variants_agree(g1, variant):
     fragments, 4 persistent; conv_f16x3.hip) must give the logits of the default form (three workgroups per CU) bit for
     bit: same K order, same accumulators."""
     from pmp_vvc_tip2023_amd import engine
-    e2 = engine.Engine(0)
+    e2 = engine.Engine(0, allow_synthetic_mtt=True)
     try:
         e2.set_precision("f16x3")
         y = np.concatenate([g1["block_y"]] * 8)              # 128 blocks: several tiles per persistent workgroup at 64x64
@@ -286,7 +286,7 @@ def test_config2_full_batch_properties(eng, oracle_lib):
     assert hor[:, 0, :].all() and ver[:, :, 0].all()
     assert np.array_equal(q8[:, ::2, ::2], q8[:, 1::2, 1::2]) and q8.max() <= 3 and set(np.unique(d8)) <= {-1, 0, 1}
     idx = np.arange(0, n, n // 24)[:24]
-    wq, _ = W.load_net_weights("Luma_Q", 22); wbd, _ = W.load_net_weights("Luma_MSBD", 22)
+    wq, _ = W.load_net_weights("Luma_Q", 22); wbd, _ = W.load_net_weights("Luma_MSBD", 22, allow_synthetic=True)
     o_q, o_bt, o_dire = O.infer_qbd(wq, wbd, O.luma_input(y[idx]), True)
     assert np.abs(qt[idx] - o_q).max() < TOL and np.abs(bt[idx] - o_bt).max() < TOL and np.abs(dire[idx] - o_dire).max() < TOL
 
@@ -332,7 +332,8 @@ def test_driver_end_to_end_files(eng, oracle_lib, tmp_path):
         with open(cfg / (name + ".cfg"), "w") as f:
             f.write("InputFile                     : %s   # comment\nInputBitDepth                 : %d\n" % (fn, bd))
     D.main(["--jobID", "j1", "--inputDir", str(inp), "--outDir", str(out), "--seqTable", "table.txt", "--cfgDir", str(cfg),
-            "--ssRatio", "2", "--startSeqID", "0", "--seqNum", "2", "--batchSize", "5", "--strictBatch", "--qps", "22,37"])
+            "--ssRatio", "2", "--startSeqID", "0", "--seqNum", "2", "--batchSize", "5", "--strictBatch", "--qps", "22,37", "--binary",
+            "--allowSyntheticMTT"])
     for name, fn, w, h, fr, bd in seqs:
         y, u, v = planes[name]
         by, bu, bv = oracle_lib.cut_blocks(y[::2], u[::2], v[::2], bd)
@@ -344,13 +345,19 @@ def test_driver_end_to_end_files(eng, oracle_lib, tmp_path):
                 oracle_lib.seq_post_process(qt, bt, dire, comp, nf, w, h, po)
                 got = out / "j1" / "PartitionMat" / ("%s_%s_QP%d_PartitionMat.txt" % (fn[:-4], comp, qp))
                 assert open(got, "rb").read() == open(po, "rb").read(), (name, comp, qp)
+                # --binary: the side-channel file next to it holds the same numbers
+                from pmp_vvc_tip2023_amd import engine as E
+                f_, h_, w_, bh_, bv_, bq_, bd_ = E.read_partition_binary(str(got)[:-4] + ".pmpb")
+                th_, tv_, tq_, td_ = E.read_partition_file(str(got), nf, h, w)
+                assert (f_, h_, w_) == (nf, h, w) and np.array_equal(bh_, th_) and np.array_equal(bv_, tv_)
+                assert np.array_equal(bq_, tq_) and np.array_equal(bd_, td_)
     rows = open(out / "j1" / "Time_Sta_0_2.txt").read().strip().split("\n")
     assert len(rows) == 2 * 4 and all(r.count(",") == 5 for r in rows)
     # the default run kept the blocks device-resident; the reference-style host block arrays give the same bytes
     out2 = tmp_path / "out_host"
     D.main(["--jobID", "j1", "--inputDir", str(inp), "--outDir", str(out2), "--seqTable", "table.txt", "--cfgDir", str(cfg),
-            "--ssRatio", "2", "--startSeqID", "0", "--seqNum", "2", "--batchSize", "5", "--qps", "22,37", "--hostBlocks"])
-    names = sorted(os.listdir(out / "j1" / "PartitionMat"))
+            "--ssRatio", "2", "--startSeqID", "0", "--seqNum", "2", "--batchSize", "5", "--qps", "22,37", "--hostBlocks", "--allowSyntheticMTT"])
+    names = sorted(n for n in os.listdir(out / "j1" / "PartitionMat") if n.endswith(".txt"))
     assert names == sorted(os.listdir(out2 / "j1" / "PartitionMat")) and len(names) == 8
     for nm in names:
         assert open(out / "j1" / "PartitionMat" / nm, "rb").read() == open(out2 / "j1" / "PartitionMat" / nm, "rb").read(), nm
@@ -415,7 +422,7 @@ def test_driver_two_ranks_equal_one_rank(tmp_path):
             f.write(y[i].tobytes()); f.write(u[i].tobytes()); f.write(v[i].tobytes())
     with open(cfg / "SeqC.cfg", "w") as f:
         f.write("InputFile : SeqC_320x192_30.yuv\nInputBitDepth : 8\n")
-    common = ["--inputDir", str(inp), "--seqTable", "table.txt", "--cfgDir", str(cfg), "--ssRatio", "1", "--seqNum", "1", "--qps", "22,32"]
+    common = ["--inputDir", str(inp), "--seqTable", "table.txt", "--cfgDir", str(cfg), "--ssRatio", "1", "--seqNum", "1", "--qps", "22,32", "--allowSyntheticMTT"]
     D.main(["--jobID", "one", "--outDir", str(tmp_path / "o1")] + common)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

@@ -8,7 +8,7 @@ from pmp_vvc_tip2023_amd import engine, synth
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 variants = [int(v) for v in sys.argv[2:]] or [0, 1, 2]
 n = 1024
-eng = engine.Engine(0)
+eng = engine.Engine(0, allow_synthetic_mtt=True)
 eng.load("Luma", 22)
 dev = torch.device("cuda:0")
 y, _, _ = synth.recipe_r_blocks(n, 1)

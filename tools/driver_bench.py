@@ -21,7 +21,7 @@ with open(os.path.join(inp, fn), "wb") as f:
 open(os.path.join(inp, "table.txt"), "w").write("%s,%s,%d,%d,%d,30\n#end!!!!\n" % (name, fn, W, H, F))
 open(os.path.join(cfg, name + ".cfg"), "w").write("InputFile : %s\nInputBitDepth : 8\n" % fn)
 args = ["--jobID", "b", "--inputDir", inp, "--outDir", out, "--seqTable", "table.txt", "--cfgDir", cfg, "--ssRatio", "1",
-        "--startSeqID", "0", "--seqNum", "1"]
+        "--startSeqID", "0", "--seqNum", "1", "--allowSyntheticMTT"]
 D.main(args)            # warm-up (weights, workspace, first-touch)
 t0 = time.time()
 D.main(args)

@@ -7,7 +7,7 @@ from pmp_vvc_tip2023_amd import engine
 
 g1 = np.load(os.path.join(ROOT, "tests", "golden", "g1_qt.npz"))
 g2 = np.load(os.path.join(ROOT, "tests", "golden", "g2_msbd.npz"))
-eng = engine.Engine(0)
+eng = engine.Engine(0, allow_synthetic_mtt=True)
 for mode in ("f16x3", "bf16x6", "fp32"):
     eng.set_precision(mode)
     worst_q, worst_m, where = 0.0, 0.0, ""
