@@ -9,7 +9,12 @@ Unit: the nets consume 64x64 blocks (+4 px context); one VTM CTU is 128x128 = 4 
 (one library pass: the default chunk is 4096 blocks) and CTU/s = blocks/s / 4 (BASELINE.md section 2).  `value` is CTU/s;
 blocks/s is reported next to it.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]        (N>1: launched by torch.distributed.run)
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1: one process per GPU.  Under torch.distributed.run (RANK / WORLD_SIZE in the environment) this process is one rank;
+started plainly with --gpus N it launches its own N rank processes - fresh children, before this process has made any GPU
+call - relays rank 0's JSON line and exits non-zero if any rank failed.  Blocks are sharded over the ranks (weak scaling:
+--ctus per GPU) with no data-path collective; the one exchange is the RCCL gather of the packed split-flag records to rank 0.
 
 Rank 0 prints ONE JSON line on stdout; diagnostics go to stderr.
 """
@@ -100,6 +105,75 @@ def cpu_baseline(sample_blocks, seed, eng=None):
     return out, parity
 
 
+def measure_extras(eng, args, dev, n, y, u, v, step):
+    """Side measurements AFTER the timed region (they never enter `value`), N = 1 only:
+    * e2e_host_buffers: the same step through the host-pointer boundary (pmp_infer_postprocess: H2D of the u8 blocks, the
+      pass, D2H of the split flags) - SURVEY.md 8(d) config 2's "end-to-end" number next to the device-resident one;
+    * chroma and per-QP luma throughput of the device-resident step (3 steps each)."""
+    out = {}
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t) / reps
+
+    chroma = args.comp == "Chroma"
+    dt = timed(lambda: eng.infer_postprocess(args.comp, args.qp, y, u if chroma else None, v if chroma else None), 3)
+    h2d = n * (68 * 68 + (2 * 34 * 34 if chroma else 0))
+    out["e2e_host_buffers"] = {"value": round(n / 4.0 / dt, 2), "unit": "CTU/s", "ms_per_step": round(dt * 1e3, 3), "steps": 3,
+                               "h2d_bytes_per_step": h2d, "d2h_bytes_per_step": n * 1344,
+                               "note": "pmp_infer_postprocess on pageable host buffers: H2D + pass + D2H, synchronised per step"}
+    if args.comp == "Luma" and args.qp == 22:
+        per_qp = {}
+        for qp in (22, 27, 32, 37):
+            eng.load("Luma", qp)
+            per_qp[str(qp)] = round(n / 4.0 / timed(lambda: step("Luma", qp), 3), 2)
+        eng.load("Chroma", 22)
+        out["extra"] = {"luma_ctu_per_s_by_qp": per_qp, "chroma_qp22_ctu_per_s": round(n / 4.0 / timed(lambda: step("Chroma", 22), 3), 2),
+                        "note": "device-resident step, 3 steps each after 1 warm-up; same blocks; chroma counts the 64x64-luma-area "
+                                "block (34x34 chroma inputs) as the unit, as the luma figure does"}
+    return out
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (this parent never touches the GPU - a
+    process that has initialised HIP must not be replaced or forked into ranks) and relay rank 0's stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+               PMP_BENCH_CHILD="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    out0 = b""
+    rc = 0
+    try:
+        out0 = procs[0].communicate()[0]
+        for p in procs:
+            p.wait()
+            rc = rc or p.returncode
+    except BaseException:
+        rc = rc or 1
+        raise
+    finally:
+        for p in procs:                                        # a rank that died leaves the others at a barrier: end them by PID
+            if p.poll() is None:
+                p.kill()
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return rc or (0 if out0.strip() else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,16 +189,18 @@ def main():
                     help="conv datapath: 2-term fp16 split (3 MFMA products) or 3-term bf16 split (6 products), both "
                          "fp32-equivalent, or exact fp32 MFMA")
     ap.add_argument("--breakdown", action="store_true", help="extra pass with every kernel class timed (stderr)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the side measurements after the timed region (host-buffer end-to-end rate, chroma, per-QP luma)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # no launcher: become one (before any GPU call)
+        raise SystemExit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         log("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
     n_gpus = world if world > 1 else 1
-    if args.gpus > 1 and world == 1:
-        log("--gpus %d without torch.distributed.run: running the single-GPU workload" % args.gpus)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
@@ -160,22 +236,21 @@ def main():
     d_y = torch.from_numpy(y).to(dev)
     d_u = torch.from_numpy(u).to(dev)
     d_v = torch.from_numpy(v).to(dev)
-    # one packed result record per block: hor[256] | ver[256] | qt[64] | dire[768] = 1344 bytes
+    # one packed result record per block, written by the post-processing kernel itself (include/pmp.h, PMP_RECORD_BYTES):
+    # hor[256] | ver[256] | qt[64] | dire[768] = 1344 bytes - the unit of the gather
     res = torch.empty((n, 1344), dtype=torch.uint8, device=dev)
-    hor = torch.empty((n, 256), dtype=torch.uint8, device=dev); ver = torch.empty_like(hor)
-    q8 = torch.empty((n, 64), dtype=torch.uint8, device=dev); d8 = torch.empty((n, 768), dtype=torch.int8, device=dev)
     gathered = torch.empty((world * n, 1344), dtype=torch.uint8, device=dev) if (n_gpus > 1 and rank == 0) else None
     pu = d_u.data_ptr() if args.comp == "Chroma" else None
     pv = d_v.data_ptr() if args.comp == "Chroma" else None
 
-    def step():
-        eng.infer_postprocess_device(args.comp, args.qp, d_y.data_ptr(), pu, pv, n, hor.data_ptr(), ver.data_ptr(),
-                                     q8.data_ptr(), d8.data_ptr())
+    def step(comp=args.comp, qp=args.qp):
+        chroma = comp == "Chroma"
+        eng.infer_postprocess_records_device(comp, qp, d_y.data_ptr(), d_u.data_ptr() if chroma else None,
+                                             d_v.data_ptr() if chroma else None, n, res.data_ptr())
         if n_gpus > 1:
-            # the path's only exchange: split flags of every shard go to rank 0, which owns the file writer
-            res[:, :256] = hor; res[:, 256:512] = ver; res[:, 512:576] = q8; res[:, 576:] = d8.view(torch.uint8)
+            # the path's only exchange: split-flag records of every shard go to rank 0, which owns the file writer
             if dist.get_backend() == "nccl":
-                dist.gather(res, list(gathered.split(n)) if rank == 0 else None, dst=0)
+                dist.gather(res, list(gathered.split(n)) if rank == 0 else None, dst=0)      # RCCL, device to device over xGMI
             else:
                 rc = res.cpu()
                 dist.gather(rc, [torch.empty_like(rc) for _ in range(world)] if rank == 0 else None, dst=0)
@@ -220,7 +295,10 @@ def main():
                 traffic = None
         peak = PEAK_TFLOPS[args.precision]
         roof = {"bound": "mfma", "kernel": DOMINANT, "achieved": round(achieved, 2), "peak": round(peak, 1),
-                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "peak_basis": PEAK_NOTE[args.precision],
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                "traffic_source": "profiles/pmc_traffic.json: rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE) of this kernel build, "
+                                  "scaled to the blocks per launch; not collected in this run" if traffic is not None else None,
+                "peak_basis": PEAK_NOTE[args.precision],
                 "launches": launches, "avg_launch_ms": round(ms / launches, 4),
                 "flop_per_launch": flops / launches}
 
@@ -236,6 +314,10 @@ def main():
             log("  %-20s launches %6.2f  %9.3f ms per 1024 blocks  %7.2f TFLOP/s" % (k, ln * per, kms * per, (fl / (kms * 1e-3) / 1e12) if kms else 0))
         log("  sum of kernel time %.3f ms per 1024 blocks (step = %d blocks)" % (tot * per, n))
         eng.ktime_enable(0)
+
+    extras = {}
+    if rank == 0 and n_gpus == 1 and not args.no_extras:
+        extras = measure_extras(eng, args, dev, n, y, u, v, step)
 
     if rank == 0:
         out = {
@@ -255,6 +337,7 @@ def main():
             "net_tflops": round(blocks_per_s * FLOP_PER_BLOCK[args.comp] / 1e12, 2),
             "roofline": roof,
         }
+        out.update(extras)
         if args.cpu_sample > 0 and n_gpus == 1 and args.comp == "Luma":
             out["cpu_baseline"], out["parity"] = cpu_baseline(args.cpu_sample, 1, eng)
         else:

@@ -43,6 +43,7 @@ extern "C" {
 #define PMP_E_IO (-4)        /* file could not be written */
 #define PMP_E_NOMEM (-5)     /* device or host allocation failed */
 #define PMP_E_NODEVICE (-6)  /* no gfx950 device: there is no CPU fallback */
+#define PMP_E_RANGE (-7)     /* f16x3 datapath: an activation left the fp16 range and the policy is PMP_SAT_ERROR */
 
 enum { PMP_LUMA = 0, PMP_CHROMA = 1 };
 enum { PMP_NET_LUMA_Q = 0, PMP_NET_LUMA_MSBD = 1, PMP_NET_CHROMA_Q = 2, PMP_NET_CHROMA_MSBD = 3 };
@@ -69,20 +70,41 @@ int pmp_destroy(pmp_ctx *ctx);
 int pmp_set_stream(pmp_ctx *ctx, void *hip_stream);
 int pmp_synchronize(pmp_ctx *ctx);
 
-/* Blocks processed per pass (activation workspace is sized for it); n > chunk is looped.  1..4096, default 4096
- * (about 60 GB of workspace for a full luma chunk; the workspace only grows to what the largest pass so far needed). */
+/* Blocks processed per pass; n > chunk is looped.  1..4096 (32-bit element offsets inside one activation tensor), default
+ * 4096.  The activation workspace is sized for the blocks a pass actually runs, min(n, chunk), and tensors share memory once
+ * their last consumer is enqueued: about 2.1 MB per luma block on the default datapath (8.4 GB for a full 4096-block pass,
+ * 9 MB for a 4-block call); it only grows, to what the largest pass so far needed.  pmp_get_workspace_bytes reports it. */
 int pmp_set_chunk(pmp_ctx *ctx, int blocks);
+int64_t pmp_get_workspace_bytes(const pmp_ctx *ctx);
 
 /* Convolution datapath.  All three are fp32-accurate; results differ in the last bits only.
  *   PMP_PRECISION_F32    v_mfma_f32_16x16x4_f32, exact fp32 fmaf chain
  *   PMP_PRECISION_BF16X6 every fp32 operand carried as 3 bf16 terms, 6 bf16 MFMA products, fp32 accumulate
  *   PMP_PRECISION_F16X3  (default) every fp32 operand carried as 2 fp16 terms (weights pre-scaled by a power of two),
- *                        3 fp16 MFMA products, fp32 accumulate; activations beyond +-65504 saturate */
+ *                        3 fp16 MFMA products, fp32 accumulate; activations beyond +-65504 would saturate: guarded, see below */
 #define PMP_PRECISION_F32 0
 #define PMP_PRECISION_BF16X6 1
 #define PMP_PRECISION_F16X3 2
 int pmp_set_precision(pmp_ctx *ctx, int mode);
 int pmp_get_precision(const pmp_ctx *ctx);
+
+/* Range guard of the f16x3 datapath.  Its activations travel as two fp16 terms, so a value beyond +-65504 is clamped when it
+ * is stored (the reference's nets stay below 3e3 on 8-bit content with the trained QT weights; trained MTT weights are not
+ * in the reference checkout).  Every kernel that stores such a tensor raises a per-context device flag when the clamp fires.
+ *   PMP_SAT_RERUN (default)  each pmp_infer* call waits for its passes, reads the flag, and if it fired runs the WHOLE call
+ *                            again on the bf16x6 datapath (no range limit, fp32-equivalent): results are always right; the
+ *                            *_device entry points therefore return with their work complete, not merely enqueued
+ *   PMP_SAT_ERROR            same check, but the call returns PMP_E_RANGE instead of re-running
+ *   PMP_SAT_IGNORE           no check and no synchronisation (the *_device calls stay asynchronous); the caller polls
+ * pmp_get_saturation synchronises and returns 1 if any inference call of this context saturated since the last
+ * pmp_clear_saturation (0 otherwise, negative on error); pmp_get_saturation_reruns counts the calls that were re-run. */
+#define PMP_SAT_RERUN 0
+#define PMP_SAT_ERROR 1
+#define PMP_SAT_IGNORE 2
+int pmp_set_saturation_policy(pmp_ctx *ctx, int policy);
+int pmp_get_saturation(pmp_ctx *ctx);
+int64_t pmp_get_saturation_reruns(const pmp_ctx *ctx);
+int pmp_clear_saturation(pmp_ctx *ctx);
 
 /* Caller keeps ownership of blob/descs; the library re-packs into its kernel layouts in device memory.
  * Every tensor the net needs must be present with the reference's shape (else PMP_E_INVALID). */
@@ -110,6 +132,16 @@ int pmp_infer_postprocess_device(pmp_ctx *ctx, int comp, int qp, const uint8_t *
                                  const uint8_t *d_block_u, const uint8_t *d_block_v, int64_t n, uint8_t *d_hor,
                                  uint8_t *d_ver, uint8_t *d_qt_u8, int8_t *d_dire_i8, float *d_qt, float *d_bt,
                                  float *d_dire);
+
+/* ---- the same with one packed RECORD per block, the unit the multi-GPU path gathers to the rank that writes the file
+ *      (counterpart of nn.DataParallel's gather, Inference_QBD.py:223-224):
+ *        u8 rec[n][PMP_RECORD_BYTES] = hor[256] | ver[256] | qt_u8[64] | dire_i8[768]
+ *      written directly by the post-processing kernel (no repacking pass); d_rec must be 4-byte aligned. ---- */
+#define PMP_RECORD_BYTES 1344
+int pmp_postprocess_records_device(pmp_ctx *ctx, int comp, const float *d_qt, const float *d_bt, const float *d_dire,
+                                   int64_t n, uint8_t *d_rec);
+int pmp_infer_postprocess_records_device(pmp_ctx *ctx, int comp, int qp, const uint8_t *d_block_y, const uint8_t *d_block_u,
+                                         const uint8_t *d_block_v, int64_t n, uint8_t *d_rec);
 
 /* ---- block cutter: output_block_yuv (Inference_QBD.py:104-149).  Planes y[F][H][W], u,v[F][H/2][W/2];
  *      bitdepth 8 -> uint8 samples, 10 -> uint16 samples reduced with round-half-even(x/4), clipped to 255.

@@ -10,7 +10,7 @@ HOSTASAN_LIB_PATH = os.path.join(_HERE, "libpmp_hostasan.so")      # make hostas
 
 PMP_LUMA, PMP_CHROMA = 0, 1
 NET_IDS = {"Luma_Q": 0, "Luma_MSBD": 1, "Chroma_Q": 2, "Chroma_MSBD": 3}
-ERRORS = {-1: "PMP_E_INVALID", -2: "PMP_E_HIP", -3: "PMP_E_NOWEIGHTS", -4: "PMP_E_IO", -5: "PMP_E_NOMEM", -6: "PMP_E_NODEVICE"}
+ERRORS = {-1: "PMP_E_INVALID", -2: "PMP_E_HIP", -3: "PMP_E_NOWEIGHTS", -4: "PMP_E_IO", -5: "PMP_E_NOMEM", -6: "PMP_E_NODEVICE", -7: "PMP_E_RANGE"}
 
 
 class PmpError(RuntimeError):
@@ -33,8 +33,13 @@ SIGNATURES = {
     "pmp_set_stream": (_I, [_VP, _VP]),
     "pmp_synchronize": (_I, [_VP]),
     "pmp_set_chunk": (_I, [_VP, _I]),
+    "pmp_get_workspace_bytes": (_I64, [_VP]),
     "pmp_set_precision": (_I, [_VP, _I]),
     "pmp_get_precision": (_I, [_VP]),
+    "pmp_set_saturation_policy": (_I, [_VP, _I]),
+    "pmp_get_saturation": (_I, [_VP]),
+    "pmp_get_saturation_reruns": (_I64, [_VP]),
+    "pmp_clear_saturation": (_I, [_VP]),
     "pmp_load_weights": (_I, [_VP, _I, _I, _VP, C.POINTER(TensorDesc), _I]),
     "pmp_has_weights": (_I, [_VP, _I, _I]),
     "pmp_infer": (_I, [_VP, _I, _I, _VP, _VP, _VP, _I64, _VP, _VP, _VP]),
@@ -43,6 +48,8 @@ SIGNATURES = {
     "pmp_postprocess_device": (_I, [_VP, _I, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP]),
     "pmp_infer_postprocess": (_I, [_VP, _I, _I, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "pmp_infer_postprocess_device": (_I, [_VP, _I, _I, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "pmp_postprocess_records_device": (_I, [_VP, _I, _VP, _VP, _VP, _I64, _VP]),
+    "pmp_infer_postprocess_records_device": (_I, [_VP, _I, _I, _VP, _VP, _VP, _I64, _VP]),
     "pmp_cut_blocks": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP]),
     "pmp_cut_blocks_device": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP]),
     "pmp_write_partition_file": (_I, [C.c_char_p, _I, _I, _I, _VP, _VP, _VP, _VP]),

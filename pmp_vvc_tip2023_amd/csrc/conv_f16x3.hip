@@ -577,6 +577,7 @@ __device__ __forceinline__ void h2_epilogue(const ConvX6Args &a, f32x4 (&acc)[Wa
 #pragma unroll
             for (int m = 0; m < RW; ++m) acc[m][nt] = acc[m][nt] * inv_scale;
     }
+    float amax = 0.f;   // largest activation about to be stored: the split clamps beyond +-65504 (split3.h) and the flag says so
 #pragma unroll
     for (int nt = 0; nt < CW; ++nt) {
 #pragma unroll
@@ -585,6 +586,7 @@ __device__ __forceinline__ void h2_epilogue(const ConvX6Args &a, f32x4 (&acc)[Wa
             f32x4 v = acc[m][nt];
             if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             if (a.gate) v *= load_split2_4(a.gate + off, a.gate_stride);
+            amax = sat_amax4(amax, v);
             acc[m][nt] = v;
         }
         if (!a.pool) {
@@ -613,6 +615,7 @@ __device__ __forceinline__ void h2_epilogue(const ConvX6Args &a, f32x4 (&acc)[Wa
             }
         }
     }
+    if (!a.out_f32) sat_report(a.sat, amax);   // fp32 outputs are not clamped
 }
 
 template <int KH, int KW>
@@ -706,10 +709,15 @@ hipError_t launch_conv_h2(hipStream_t s, const ConvX6Args &a_in)
 
 // ---- format converters ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void f32_to_split2_kernel(const float *__restrict__ x, unsigned short *__restrict__ out,
-                                                            size_t n4, size_t plane_stride)
+                                                            size_t n4, size_t plane_stride, unsigned *sat)
 {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
-        store_split2_4(out + i * 4, plane_stride, *reinterpret_cast<const f32x4 *>(x + i * 4));
+    float amax = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + i * 4);
+        amax = sat_amax4(amax, v);
+        store_split2_4(out + i * 4, plane_stride, v);
+    }
+    sat_report(sat, amax);
 }
 
 __global__ __launch_bounds__(256) void split2_to_f32_kernel(const unsigned short *__restrict__ x, float *__restrict__ out,
@@ -719,11 +727,11 @@ __global__ __launch_bounds__(256) void split2_to_f32_kernel(const unsigned short
         *reinterpret_cast<f32x4 *>(out + i * 4) = load_split2_4(x + i * 4, plane_stride);
 }
 
-hipError_t launch_f32_to_split2(hipStream_t s, const float *x, unsigned short *out, size_t n, size_t plane_stride)
+hipError_t launch_f32_to_split2(hipStream_t s, const float *x, unsigned short *out, size_t n, size_t plane_stride, unsigned *sat)
 {
     const size_t n4 = n / 4;
     const unsigned grid = (unsigned)((n4 + 255) / 256 > 16384 ? 16384 : (n4 + 255) / 256);
-    if (n4) hipLaunchKernelGGL(f32_to_split2_kernel, dim3(grid), dim3(256), 0, s, x, out, n4, plane_stride);
+    if (n4) hipLaunchKernelGGL(f32_to_split2_kernel, dim3(grid), dim3(256), 0, s, x, out, n4, plane_stride, sat);
     return hipGetLastError();
 }
 

@@ -63,7 +63,7 @@ __device__ __forceinline__ void stem_conv(const float *__restrict__ planes, cons
             const size_t o = out_n + (((size_t)(c >> 4) * OUT + (y0 + r)) * OUT + x) * 16 + (c & 15);
             f32x4 v0 = {fmaxf(acc[r][0], 0.f), fmaxf(acc[r][1], 0.f), fmaxf(acc[r][2], 0.f), fmaxf(acc[r][3], 0.f)};
             f32x4 v1 = {fmaxf(acc[r][4], 0.f), fmaxf(acc[r][5], 0.f), fmaxf(acc[r][6], 0.f), fmaxf(acc[r][7], 0.f)};
-            if (FMT != FMT_F32) { store_fmt4<FMT>(out.s3 + o, out.stride, v0); store_fmt4<FMT>(out.s3 + o + 4, out.stride, v1); }
+            if (FMT != FMT_F32) { out.store4(o, v0); out.store4(o + 4, v1); }
             else { *reinterpret_cast<f32x4 *>(out.f32 + o) = v0; *reinterpret_cast<f32x4 *>(out.f32 + o + 4) = v1; }
         }
     }
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
     __syncthreads();
 
     const size_t out_n = (size_t)n * 2 * OUT * OUT * 16;
-    const ActOut out{a.out, a.out_s3, a.s3_stride, FMT};
+    const ActOut out{a.out, a.out_s3, a.s3_stride, FMT, a.sat};
     constexpr int COLS_PER_WG = 256 / OUT;       // luma: 4 row-bands of 16 rows; chroma: 8 bands of 4 rows
     constexpr int BAND = OUT / COLS_PER_WG;
     const int x = tid % OUT, band = tid / OUT;
@@ -175,6 +175,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(StemArgs a)
                 qv = a.q[(size_t)n * 64 + ((r - P) / SC) * 8 + (c - P) / SC];
             }
             _Float16 q0, q1;
+            sat_report(a.sat, fabsf(qv));
             split2(qv, q0, q1);
             h0[(CIN - 1) * PS * RS + i] = q0; h1[i] = q1;
         }
@@ -197,6 +198,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(StemArgs a)
         for (int j = 0; j < 8; ++j) v[j] = p[j];
         return v;
     };
+    float amax = 0.f;   // largest stored activation: beyond +-65504 the split clamps, and the context's flag is raised
     for (int b = wave; b < NBATCH; b += 4) {
         const int seg = b % SEGS, y0 = (b / SEGS) * RB, x0 = seg * 16;
         // row index clamped: the window runs up to STEP-1 rows past the last row a real tap needs (zero weights there)
@@ -245,10 +247,12 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(StemArgs a)
                 f32x4 v = acc[m][nt] * inv_scale + bias;
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                 const size_t o = out_n + (((size_t)nt * OUT + (y0 + m)) * OUT + x0 + xl) * 16 + g * 4;
+                amax = sat_amax4(amax, v);
                 store_split2_4(a.out_s3 + o, a.s3_stride, v);
             }
         }
     }
+    sat_report(a.sat, amax);
 }
 
 template <bool LUMA, bool MSBD>
@@ -479,9 +483,9 @@ __global__ __launch_bounds__(256) void multipool_concat_kernel(const float *__re
     }
 }
 
-hipError_t launch_multipool_concat(hipStream_t s, const float *x5, float *x6, int N, unsigned short *x6_s3, size_t s3_stride, int fmt)
+hipError_t launch_multipool_concat(hipStream_t s, const float *x5, float *x6, int N, unsigned short *x6_s3, size_t s3_stride, int fmt, unsigned *sat)
 {
-    hipLaunchKernelGGL(multipool_concat_kernel, dim3(N * 2), dim3(256), 0, s, x5, ActOut{x6, x6_s3, s3_stride, fmt});
+    hipLaunchKernelGGL(multipool_concat_kernel, dim3(N * 2), dim3(256), 0, s, x5, ActOut{x6, x6_s3, s3_stride, fmt, sat});
     return hipGetLastError();
 }
 
@@ -501,11 +505,11 @@ __global__ __launch_bounds__(256) void att_input_kernel(const float *__restrict_
 }
 
 hipError_t launch_att_input(hipStream_t s, const float *q, const float *bt, const float *dire, int layer, float *out,
-                            int N, int S, unsigned short *out_s3, size_t s3_stride, int fmt)
+                            int N, int S, unsigned short *out_s3, size_t s3_stride, int fmt, unsigned *sat)
 {
     const size_t total = (size_t)N * S * S;
     hipLaunchKernelGGL(att_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, q, bt, dire, layer,
-                       ActOut{out, out_s3, s3_stride, fmt}, N, S);
+                       ActOut{out, out_s3, s3_stride, fmt, sat}, N, S);
     return hipGetLastError();
 }
 

@@ -24,6 +24,7 @@ struct Act {
     int C, H, W;   // C padded to 16
     bool split;
     size_t stride; // elements between split planes
+    size_t off, bytes;   // its piece of the workspace arena (Graph::release)
     const unsigned short *s() const { return reinterpret_cast<const unsigned short *>(p); }
     unsigned short *s() { return reinterpret_cast<unsigned short *>(p); }
 };
@@ -36,14 +37,24 @@ struct Graph {
     bool x6() const { return c->precision != 0; }      // a split datapath (bf16x6 or f16x3) is active
     bool h2() const { return c->precision == 2; }
     int fmt() const { return c->precision; }           // split3.h: 0 fp32, 1 split-3, 2 split-2
+    unsigned *sat() const { return h2() ? c->d_sat : nullptr; }   // f16x3: the context's sticky saturation flag
 
+    // Tensors are sized for the n blocks of this pass (not for the chunk) and give their bytes back with release().
     Act alloc(int C, int H, int W, bool split)
     {
         const int cp = (C + 15) & ~15;
-        const size_t elems = (size_t)c->chunk * cp * H * W;
-        // split-3: 3 planes of 2-byte elements = 1.5 floats per element; split-2: 2 planes = 1 float per element
-        float *p = c->arena.get(split && !h2() ? (elems * 3 + 1) / 2 : elems);
-        return Act{p, cp, H, W, split, elems};
+        const size_t elems = (size_t)n * cp * H * W;
+        // split-3: 3 planes of 2-byte elements = 6 bytes per element; split-2: 2 planes = 4; fp32: 4
+        const size_t bytes = elems * (split && !h2() ? 6 : 4);
+        const size_t off = c->arena.take(bytes);
+        return Act{c->arena.ptr(off), cp, H, W, split, elems, off, bytes};
+    }
+
+    // The tensor's last consumer has been enqueued (one in-order stream): later allocations may reuse its bytes.
+    void release(Act &a)
+    {
+        if (a.bytes) c->arena.give(a.off, a.bytes);
+        a.bytes = 0;
     }
 
     bool check(hipError_t e, const char *what)
@@ -60,14 +71,14 @@ struct Graph {
         return K_CONV_OTHER;
     }
 
-    // fp32 tensor -> split-3 (no-op in fp32 mode)
+    // fp32 tensor -> split planes of the active datapath (no-op in fp32 mode or for a tensor that is split already)
     Act to_conv_input(const Act &x)
     {
         if (!x6() || x.split) return x;
         Act y = alloc(x.C, x.H, x.W, true);
         if (live()) {
             KScope ks(c, K_SMALL, 0.0);
-            if (h2()) check(launch_f32_to_split2(c->stream, x.p, y.s(), (size_t)n * x.C * x.H * x.W, y.stride), "f32_to_split2");
+            if (h2()) check(launch_f32_to_split2(c->stream, x.p, y.s(), (size_t)n * x.C * x.H * x.W, y.stride, sat()), "f32_to_split2");
             else check(launch_f32_to_split3(c->stream, x.p, y.s(), (size_t)n * x.C * x.H * x.W, y.stride), "f32_to_split3");
         }
         return y;
@@ -82,7 +93,7 @@ struct Graph {
         if (x6()) {
             ConvX6Args a{};
             a.x = x.s(); a.x_stride = x.stride;
-            if (h2()) { a.w = second ? r.w2h : r.w0h; a.out_scale = std::ldexp(1.f, -(second ? r.k2 : r.k0)); }
+            if (h2()) { a.w = second ? r.w2h : r.w0h; a.out_scale = std::ldexp(1.f, -(second ? r.k2 : r.k0)); a.sat = sat(); }
             else a.w = second ? r.w2x : r.w0x;
             if (sc_src) { a.x_sc = sc_src->s(); a.sc_stride = sc_src->stride; a.w_sc = h2() ? r.wsch : r.wscx; a.Csc = sc_src->C; }
             if (res) { a.res = res->s(); a.res_stride = res->stride; }
@@ -104,7 +115,10 @@ struct Graph {
     }
 
     // ResidualBlock (Model_QBD.py:23-44) with optional fused gate / pool.  out_f32: the consumer is not an MFMA conv.
-    Act rb(const Act &x_in, const std::string &name, bool pool = false, const Act *gate = nullptr, bool out_f32 = false)
+    // consume: the caller has no further use for x_in - its bytes are released here, and an identity-shortcut block without
+    // pooling writes its output IN PLACE over it (every thread reads the residual of exactly the elements it then stores,
+    // the convolution itself reads the intermediate t), so a trunk of such blocks needs two tensors, not three.
+    Act rb(Act &x_in, const std::string &name, bool pool = false, const Act *gate = nullptr, bool out_f32 = false, bool consume = true)
     {
         auto it = w.rb.find(name);
         if (it == w.rb.end()) { if (rc == PMP_OK) rc = set_err(c, PMP_E_INVALID, "graph: no weights for " + name); return x_in; }
@@ -113,28 +127,38 @@ struct Graph {
         const double px = (double)n * H * W;
         if (r.direct) {  // 8x8 maps: plain fp32 kernels in both modes
             Act t = alloc(r.cout, H, W, false), y = alloc(r.cout, pool ? H / 2 : H, pool ? W / 2 : W, false);
-            if (!live()) return y;
-            const Act &x = x_in;
-            ConvDirectArgs a{};
-            a.x = x.p; a.w = r.w0; a.out = t.p;
-            a.N = n; a.H = H; a.W = W; a.Cin = r.cin; a.CinPad = x.C; a.Cout = r.cout; a.CoutPad = t.C;
-            a.KH = a.KW = r.k; a.relu = 1;
-            { KScope ks(c, K_SMALL, 2.0 * px * r.cout * r.cin * r.k * r.k); check(launch_conv_direct(c->stream, a), "conv_direct"); }
-            ConvDirectArgs b{};
-            b.x = t.p; b.w = r.w2; b.out = y.p;
-            b.N = n; b.H = H; b.W = W; b.Cin = r.cout; b.CinPad = t.C; b.Cout = r.cout; b.CoutPad = y.C;
-            b.KH = b.KW = r.k; b.relu = 1;
-            if (r.wsc) { b.x_sc = x.p; b.w_sc = r.wsc; b.Csc = r.cin; b.CscPad = x.C; }
-            else b.res = x.p;
-            { KScope ks(c, K_SMALL, 2.0 * px * r.cout * (r.cout * r.k * r.k + (r.wsc ? r.cin : 0))); check(launch_conv_direct(c->stream, b), "conv_direct"); }
+            if (live()) {
+                const Act &x = x_in;
+                ConvDirectArgs a{};
+                a.x = x.p; a.w = r.w0; a.out = t.p;
+                a.N = n; a.H = H; a.W = W; a.Cin = r.cin; a.CinPad = x.C; a.Cout = r.cout; a.CoutPad = t.C;
+                a.KH = a.KW = r.k; a.relu = 1;
+                { KScope ks(c, K_SMALL, 2.0 * px * r.cout * r.cin * r.k * r.k); check(launch_conv_direct(c->stream, a), "conv_direct"); }
+                ConvDirectArgs b{};
+                b.x = t.p; b.w = r.w2; b.out = y.p;
+                b.N = n; b.H = H; b.W = W; b.Cin = r.cout; b.CinPad = t.C; b.Cout = r.cout; b.CoutPad = y.C;
+                b.KH = b.KW = r.k; b.relu = 1;
+                if (r.wsc) { b.x_sc = x.p; b.w_sc = r.wsc; b.Csc = r.cin; b.CscPad = x.C; }
+                else b.res = x.p;
+                { KScope ks(c, K_SMALL, 2.0 * px * r.cout * (r.cout * r.k * r.k + (r.wsc ? r.cin : 0))); check(launch_conv_direct(c->stream, b), "conv_direct"); }
+            }
+            release(t);
+            if (consume) release(x_in);
             return y;
         }
-        const Act x = to_conv_input(x_in);
+        Act x = to_conv_input(x_in);
+        const bool converted = x.p != x_in.p || x.off != x_in.off;
+        if (converted && consume) release(x_in);
+        const bool x_dead = converted || consume;           // x's bytes are ours to reuse after this block
         Act t = alloc(r.cout, H, W, x6());
-        Act y = alloc(r.cout, pool ? H / 2 : H, pool ? W / 2 : W, x6() && !out_f32);
+        const bool y_split = x6() && !out_f32;
+        const bool in_place = x_dead && !r.wsc && !pool && x.split == y_split && x.C == ((r.cout + 15) & ~15);
+        Act y = in_place ? x : alloc(r.cout, pool ? H / 2 : H, pool ? W / 2 : W, y_split);
         conv(x, r, false, nullptr, nullptr, nullptr, false, t, 2.0 * px * r.cout * r.cin * r.k * r.k, kclass(r.k, r.cin, r.cout));
         conv(t, r, true, r.wsc ? &x : nullptr, r.wsc ? nullptr : &x, gate, pool, y,
              2.0 * px * r.cout * (r.cout * r.k * r.k + (r.wsc ? r.cin : 0)), kclass(r.k, r.cout, r.cout));
+        release(t);
+        if (x_dead && !in_place) release(x);
         return y;
     }
 
@@ -144,7 +168,7 @@ struct Graph {
         Act o = alloc(32, S, S, x6());     // bf16x6 mode: the stem writes split-3 planes directly
         if (!live()) return o;
         StemArgs a{by, bu, bv, q, w.stem_w, w.stem_b, o.split ? nullptr : o.p, n, o.split ? o.s() : nullptr, o.stride, fmt(),
-                   h2() ? w.stem_wh : nullptr, std::ldexp(1.f, -w.stem_k)};
+                   h2() ? w.stem_wh : nullptr, std::ldexp(1.f, -w.stem_k), sat()};
         const int cin = (luma ? 1 : 3) + (msbd ? 1 : 0), k1 = luma ? 9 : 5, k2 = luma ? 5 : 3;
         const double macs = msbd ? (double)cin * (k1 * k1 * 16 + 2 * k1 * k2 * 8) : (double)cin * k1 * k1 * 32;
         KScope ks(c, K_STEM, 2.0 * n * S * S * macs);
@@ -175,12 +199,14 @@ int forward_q(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, con
     Act x6 = g.alloc(128, 16, 16, g.x6());
     if (g.live()) {
         KScope ks(c, K_SMALL, 0.0);
-        g.check(launch_multipool_concat(c->stream, x5.p, x6.split ? nullptr : x6.p, n, x6.split ? x6.s() : nullptr, x6.stride, g.fmt()), "multipool_concat");
+        g.check(launch_multipool_concat(c->stream, x5.p, x6.split ? nullptr : x6.p, n, x6.split ? x6.s() : nullptr, x6.stride, g.fmt(), g.sat()), "multipool_concat");
     }
+    g.release(x5);
     Act x7 = g.rb(x6, "resblock_q4");
     Act x8 = g.rb(x7, "resblock_q5", true, nullptr, true);    // fp32: 8x8 tail runs on the direct kernel
     Act x9 = g.rb(x8, "resblock_q6");
     g.head(x9, 0, -1, qt, nullptr, nullptr);
+    g.release(x9);
     return g.rc;
 }
 
@@ -193,30 +219,43 @@ int forward_msbd(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, 
     x = g.rb(x, "trunk_M1.0");
     for (int i = 1; i < 5; ++i) x = g.rb(x, "trunk_M1." + std::to_string(i));
     Act x4 = g.rb(x, "trunk_M1.5", luma);              // luma pools after M1 (:136), chroma does not (:234)
-    x = x4;
-    for (int i = 0; i < 3; ++i) x = g.rb(x, "trunk_M2." + std::to_string(i));
+    x = g.rb(x4, "trunk_M2.0", false, nullptr, false, false);   // x4 stays: attention 2 gates it (:150)
+    for (int i = 1; i < 3; ++i) x = g.rb(x, "trunk_M2." + std::to_string(i));
     Act x5 = g.rb(x, "trunk_M2.3", true);
-    // branch B1 -> out0
-    Act b = g.rb(g.rb(g.rb(x5, "trunk_B1.0"), "trunk_B1.1"), "trunk_B1.2", false, nullptr, true);
+    // branch B1 -> out0 (x5 stays: attention 1 gates it, :143)
+    Act b = g.rb(x5, "trunk_B1.0", false, nullptr, false, false);
+    b = g.rb(b, "trunk_B1.1");
+    b = g.rb(b, "trunk_B1.2", false, nullptr, true);
     g.head(b, 0, 0, nullptr, bt, dire);
+    g.release(b);
     // attention 1 gates x5 (:140-143), branch B2 -> out1 (accumulated in the head kernel, :146)
     Act ai = g.alloc(16, 16, 16, g.x6());
     if (g.live()) {
         KScope ks(c, K_SMALL, 0.0);
-        g.check(launch_att_input(c->stream, qt, bt, dire, 0, ai.split ? nullptr : ai.p, n, 16, ai.split ? ai.s() : nullptr, ai.stride, g.fmt()), "att_input");
+        g.check(launch_att_input(c->stream, qt, bt, dire, 0, ai.split ? nullptr : ai.p, n, 16, ai.split ? ai.s() : nullptr, ai.stride, g.fmt(), g.sat()), "att_input");
     }
-    Act xb1 = g.rb(g.rb(ai, "trunk_Att1.0"), "trunk_Att1.1", false, &x5);
-    b = g.rb(g.rb(g.rb(xb1, "trunk_B2.0"), "trunk_B2.1"), "trunk_B2.2", false, nullptr, true);
+    Act a1 = g.rb(ai, "trunk_Att1.0");
+    Act xb1 = g.rb(a1, "trunk_Att1.1", false, &x5);
+    g.release(x5);
+    b = g.rb(xb1, "trunk_B2.0");
+    b = g.rb(b, "trunk_B2.1");
+    b = g.rb(b, "trunk_B2.2", false, nullptr, true);
     g.head(b, 1, 1, nullptr, bt, dire);
+    g.release(b);
     // attention 2 gates x4 at 32x32 (:147-150), branch B3 -> pool -> out2 (:151-153)
     Act aj = g.alloc(16, 32, 32, g.x6());
     if (g.live()) {
         KScope ks(c, K_SMALL, 0.0);
-        g.check(launch_att_input(c->stream, qt, bt, dire, 1, aj.split ? nullptr : aj.p, n, 32, aj.split ? aj.s() : nullptr, aj.stride, g.fmt()), "att_input");
+        g.check(launch_att_input(c->stream, qt, bt, dire, 1, aj.split ? nullptr : aj.p, n, 32, aj.split ? aj.s() : nullptr, aj.stride, g.fmt(), g.sat()), "att_input");
     }
-    Act xb3 = g.rb(g.rb(aj, "trunk_Att2.0"), "trunk_Att2.1", false, &x4);
-    b = g.rb(g.rb(g.rb(xb3, "trunk_B3.0"), "trunk_B3.1"), "trunk_B3.2", true, nullptr, true);
+    Act a2 = g.rb(aj, "trunk_Att2.0");
+    Act xb3 = g.rb(a2, "trunk_Att2.1", false, &x4);
+    g.release(x4);
+    b = g.rb(xb3, "trunk_B3.0");
+    b = g.rb(b, "trunk_B3.1");
+    b = g.rb(b, "trunk_B3.2", true, nullptr, true);
     g.head(b, 2, 2, nullptr, bt, dire);
+    g.release(b);
     return g.rc;
 }
 

@@ -74,20 +74,50 @@ static const NetWeights *find_net(pmp_ctx *c, int net_id, int qp)
     return (it == c->nets.end() || !it->second.loaded) ? nullptr : &it->second;
 }
 
+static int sync(pmp_ctx *c);
+
 // Runs forward (measure pass, then real) for n <= chunk blocks.
 template <typename F>
 static int run_graph(pmp_ctx *c, F &&fwd)
 {
     c->arena.measuring = true;
-    c->arena.off = 0;
+    c->arena.reset();
     int rc = fwd();
     if (rc != PMP_OK) return rc;
-    if ((rc = ensure(c, c->ws, c->arena.off)) != PMP_OK) return rc;
+    if ((rc = ensure(c, c->ws, c->arena.peak)) != PMP_OK) return rc;
     c->arena.base = static_cast<char *>(c->ws.p);
     c->arena.cap = c->ws.cap;
     c->arena.measuring = false;
-    c->arena.off = 0;
+    c->arena.reset();
     return fwd();
+}
+
+static int infer_passes(pmp_ctx *c, bool luma, const NetWeights &wq, const NetWeights &wb, const uint8_t *by, const uint8_t *bu,
+                        const uint8_t *bv, int64_t n, float *qt, float *bt, float *dire)
+{
+    for (int64_t o = 0; o < n; o += c->chunk) {
+        const int m = (int)((n - o) < c->chunk ? (n - o) : c->chunk);
+        const uint8_t *y = by + o * 68 * 68;
+        const uint8_t *u = bu ? bu + o * 34 * 34 : nullptr, *v = bv ? bv + o * 34 * 34 : nullptr;
+        float *q = qt + o * 64;
+        int rc = run_graph(c, [&] { return forward_q(c, luma, wq, y, u, v, m, q); });
+        if (rc != PMP_OK) return rc;
+        rc = run_graph(c, [&] { return forward_msbd(c, luma, wb, y, u, v, q, m, bt + o * 768, dire + o * 768); });
+        if (rc != PMP_OK) return rc;
+    }
+    return PMP_OK;
+}
+
+// Reads and clears the device-side saturation word (synchronises the stream).
+static int sat_fetch(pmp_ctx *c, unsigned *out)
+{
+    unsigned h = 0;
+    hipError_t e = hipMemcpyAsync(&h, c->d_sat, sizeof(h), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && h) e = hipMemsetAsync(c->d_sat, 0, sizeof(unsigned), c->stream);
+    if (e != hipSuccess) return hip_fail(c, e, "saturation flag");
+    *out = h;
+    return PMP_OK;
 }
 
 static int infer_device_impl(pmp_ctx *c, int comp, int qp, const uint8_t *by, const uint8_t *bu, const uint8_t *bv,
@@ -100,27 +130,30 @@ static int infer_device_impl(pmp_ctx *c, int comp, int qp, const uint8_t *by, co
     const NetWeights *wq = find_net(c, luma ? PMP_NET_LUMA_Q : PMP_NET_CHROMA_Q, qp);
     const NetWeights *wb = find_net(c, luma ? PMP_NET_LUMA_MSBD : PMP_NET_CHROMA_MSBD, qp);
     if (!wq || !wb) return set_err(c, PMP_E_NOWEIGHTS, "pmp_infer: weights for this (comp, qp) are not loaded");
-    for (int64_t o = 0; o < n; o += c->chunk) {
-        const int m = (int)((n - o) < c->chunk ? (n - o) : c->chunk);
-        const uint8_t *y = by + o * 68 * 68;
-        const uint8_t *u = bu ? bu + o * 34 * 34 : nullptr, *v = bv ? bv + o * 34 * 34 : nullptr;
-        float *q = qt + o * 64;
-        int rc = run_graph(c, [&] { return forward_q(c, luma, *wq, y, u, v, m, q); });
-        if (rc != PMP_OK) return rc;
-        rc = run_graph(c, [&] { return forward_msbd(c, luma, *wb, y, u, v, q, m, bt + o * 768, dire + o * 768); });
-        if (rc != PMP_OK) return rc;
-    }
-    return PMP_OK;
+    int rc = infer_passes(c, luma, *wq, *wb, by, bu, bv, n, qt, bt, dire);
+    if (rc != PMP_OK || c->precision != PMP_PRECISION_F16X3 || c->sat_policy == PMP_SAT_IGNORE || n == 0) return rc;
+    // f16x3 range guard: did any stored activation leave the fp16 range during this call?
+    unsigned fired = 0;
+    if ((rc = sat_fetch(c, &fired)) != PMP_OK || !fired) return rc;
+    c->sat_seen = 1;
+    if (c->sat_policy == PMP_SAT_ERROR)
+        return set_err(c, PMP_E_RANGE, "pmp_infer: an activation exceeded the fp16 range of the f16x3 datapath (use bf16x6 or fp32)");
+    c->sat_reruns += 1;
+    c->precision = PMP_PRECISION_BF16X6;            // three bf16 terms: fp32's exponent range, fp32-equivalent products
+    rc = infer_passes(c, luma, *wq, *wb, by, bu, bv, n, qt, bt, dire);
+    c->precision = PMP_PRECISION_F16X3;
+    if (rc == PMP_OK) rc = sync(c);
+    return rc;
 }
 
 static int post_device_impl(pmp_ctx *c, int comp, const float *qt, const float *bt, const float *dire, int64_t n,
-                            uint8_t *hor, uint8_t *ver, uint8_t *qt_u8, int8_t *dire_i8)
+                            uint8_t *hor, uint8_t *ver, uint8_t *qt_u8, int8_t *dire_i8, int record_stride = 0)
 {
     if (comp != PMP_LUMA && comp != PMP_CHROMA) return set_err(c, PMP_E_INVALID, "pmp_postprocess: bad comp");
     if (n < 0 || !qt || !bt || !dire || !hor || !ver || !qt_u8 || !dire_i8)
         return set_err(c, PMP_E_INVALID, "pmp_postprocess: null buffer or negative count");
     KScope ks(c, K_POST, 0.0);
-    hipError_t e = launch_postprocess(c->stream, qt, bt, dire, n, comp == PMP_LUMA ? 1 : 2, hor, ver, qt_u8, dire_i8);
+    hipError_t e = launch_postprocess(c->stream, qt, bt, dire, n, comp == PMP_LUMA ? 1 : 2, hor, ver, qt_u8, dire_i8, record_stride);
     return e == hipSuccess ? PMP_OK : hip_fail(c, e, "postprocess");
 }
 
@@ -187,6 +220,12 @@ int pmp_create(int device_id, pmp_ctx **out)
     c->device = device_id;
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return hip_fail(nullptr, e, "hipStreamCreate"); }
     c->stream = c->own_stream;
+    if ((e = hipMalloc((void **)&c->d_sat, 256)) != hipSuccess || (e = hipMemset(c->d_sat, 0, 256)) != hipSuccess) {
+        if (c->d_sat) hipFree(c->d_sat);
+        hipStreamDestroy(c->own_stream);
+        delete c;
+        return hip_fail(nullptr, e, "hipMalloc(saturation flag)");
+    }
     *out = c;
     return PMP_OK;
 }
@@ -202,6 +241,7 @@ int pmp_destroy(pmp_ctx *c)
     DevBuf *bufs[] = {&c->ws, &c->d_in[0], &c->d_in[1], &c->d_in[2], &c->d_logit[0], &c->d_logit[1], &c->d_logit[2],
                       &c->d_out[0], &c->d_out[1], &c->d_out[2], &c->d_out[3], &c->d_frames[0], &c->d_frames[1], &c->d_frames[2]};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
+    if (c->d_sat) hipFree(c->d_sat);
     hipStreamDestroy(c->own_stream);
     delete c;
     return PMP_OK;
@@ -224,6 +264,8 @@ int pmp_set_chunk(pmp_ctx *c, int blocks)
     return PMP_OK;
 }
 
+int64_t pmp_get_workspace_bytes(const pmp_ctx *c) { return c ? (int64_t)c->ws.cap : PMP_E_INVALID; }
+
 int pmp_set_precision(pmp_ctx *c, int mode)
 {
     CHECK_CTX(c);
@@ -236,6 +278,37 @@ int pmp_set_precision(pmp_ctx *c, int mode)
 }
 
 int pmp_get_precision(const pmp_ctx *c) { return c ? c->precision : PMP_E_INVALID; }
+
+int pmp_set_saturation_policy(pmp_ctx *c, int policy)
+{
+    CHECK_CTX(c);
+    if (policy != PMP_SAT_RERUN && policy != PMP_SAT_ERROR && policy != PMP_SAT_IGNORE)
+        return set_err(c, PMP_E_INVALID, "pmp_set_saturation_policy: PMP_SAT_RERUN, PMP_SAT_ERROR or PMP_SAT_IGNORE");
+    c->sat_policy = policy;
+    return PMP_OK;
+}
+
+int pmp_get_saturation(pmp_ctx *c)
+{
+    CHECK_CTX(c);
+    unsigned fired = 0;   // under PMP_SAT_IGNORE nothing has read the device word yet
+    int rc = sat_fetch(c, &fired);
+    if (rc != PMP_OK) return rc;
+    if (fired) c->sat_seen = 1;
+    return c->sat_seen;
+}
+
+int64_t pmp_get_saturation_reruns(const pmp_ctx *c) { return c ? c->sat_reruns : PMP_E_INVALID; }
+
+int pmp_clear_saturation(pmp_ctx *c)
+{
+    CHECK_CTX(c);
+    unsigned fired = 0;
+    int rc = sat_fetch(c, &fired);
+    c->sat_seen = 0;
+    c->sat_reruns = 0;
+    return rc;
+}
 
 int pmp_load_weights(pmp_ctx *c, int net_id, int qp, const float *blob, const pmp_tensor_desc *descs, int ndesc)
 {
@@ -277,6 +350,32 @@ int pmp_infer_postprocess_device(pmp_ctx *c, int comp, int qp, const uint8_t *by
     if (!dire) { if ((rc = ensure(c, c->d_logit[2], (size_t)(n ? n : 1) * 768 * 4))) return rc; dire = (float *)c->d_logit[2].p; }
     if ((rc = infer_device_impl(c, comp, qp, by, bu, bv, n, qt, bt, dire))) return rc;
     return post_device_impl(c, comp, qt, bt, dire, n, hor, ver, qt_u8, dire_i8);
+}
+
+// ---- packed records: hor[256] | ver[256] | qt[64] | dire[768] per block, the unit of the multi-GPU gather ------------
+static int post_records(pmp_ctx *c, int comp, const float *qt, const float *bt, const float *dire, int64_t n, uint8_t *rec)
+{
+    if (!rec || (reinterpret_cast<uintptr_t>(rec) & 3)) return set_err(c, PMP_E_INVALID, "records: null or unaligned (4 bytes) buffer");
+    return post_device_impl(c, comp, qt, bt, dire, n, rec, rec + 256, rec + 512, reinterpret_cast<int8_t *>(rec + 576), PMP_RECORD_BYTES);
+}
+
+int pmp_postprocess_records_device(pmp_ctx *c, int comp, const float *qt, const float *bt, const float *dire, int64_t n, uint8_t *rec)
+{
+    CHECK_CTX(c);
+    return post_records(c, comp, qt, bt, dire, n, rec);
+}
+
+int pmp_infer_postprocess_records_device(pmp_ctx *c, int comp, int qp, const uint8_t *by, const uint8_t *bu, const uint8_t *bv,
+                                         int64_t n, uint8_t *rec)
+{
+    CHECK_CTX(c);
+    int rc;
+    if ((rc = ensure(c, c->d_logit[0], (size_t)(n ? n : 1) * 64 * 4)) || (rc = ensure(c, c->d_logit[1], (size_t)(n ? n : 1) * 768 * 4)) ||
+        (rc = ensure(c, c->d_logit[2], (size_t)(n ? n : 1) * 768 * 4)))
+        return rc;
+    float *qt = (float *)c->d_logit[0].p, *bt = (float *)c->d_logit[1].p, *dire = (float *)c->d_logit[2].p;
+    if ((rc = infer_device_impl(c, comp, qp, by, bu, bv, n, qt, bt, dire))) return rc;
+    return post_records(c, comp, qt, bt, dire, n, rec);
 }
 
 // ---- host-pointer entry points: stage through device buffers owned by the context ------------------------

@@ -5,6 +5,7 @@
 
 #include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/pmp.h"
@@ -41,17 +42,45 @@ struct NetWeights {
     std::vector<void *> allocs;
 };
 
+// Activation workspace: a first-fit free-list allocator over one device buffer.  Every forward runs twice - a measuring
+// pass (no launches) that replays the graph's alloc/release sequence to find the peak, then the real pass, which makes the
+// same calls and therefore gets the same offsets.  All launches of a context go to one stream in order, so a tensor's
+// bytes may be handed out again as soon as its last consumer has been ENQUEUED (Graph::release).
 struct Arena {
     char *base = nullptr;
-    size_t cap = 0, off = 0;
+    size_t cap = 0, top = 0, peak = 0;
     bool measuring = false;
-    float *get(size_t nfloats)
+    std::vector<std::pair<size_t, size_t>> holes;   // (offset, bytes), sorted by offset, coalesced
+    void reset() { top = 0; peak = 0; holes.clear(); }
+    size_t take(size_t bytes)
     {
-        size_t bytes = (nfloats * sizeof(float) + 255) & ~(size_t)255;
-        float *p = measuring ? nullptr : reinterpret_cast<float *>(base + off);
-        off += bytes;
-        return p;
+        bytes = (bytes + 255) & ~(size_t)255;
+        size_t best = holes.size();
+        for (size_t i = 0; i < holes.size(); ++i)      // best fit: the smallest hole that is large enough
+            if (holes[i].second >= bytes && (best == holes.size() || holes[i].second < holes[best].second)) best = i;
+        size_t off;
+        if (best != holes.size()) {
+            off = holes[best].first;
+            if (holes[best].second == bytes) holes.erase(holes.begin() + best);
+            else { holes[best].first += bytes; holes[best].second -= bytes; }
+        } else {
+            off = top;
+            top += bytes;
+            if (top > peak) peak = top;
+        }
+        return off;
     }
+    void give(size_t off, size_t bytes)
+    {
+        bytes = (bytes + 255) & ~(size_t)255;
+        size_t i = 0;
+        while (i < holes.size() && holes[i].first < off) ++i;
+        holes.insert(holes.begin() + i, std::make_pair(off, bytes));
+        if (i + 1 < holes.size() && holes[i].first + holes[i].second == holes[i + 1].first) { holes[i].second += holes[i + 1].second; holes.erase(holes.begin() + i + 1); }
+        if (i > 0 && holes[i - 1].first + holes[i - 1].second == holes[i].first) { holes[i - 1].second += holes[i].second; holes.erase(holes.begin() + i); }
+        if (!holes.empty() && holes.back().first + holes.back().second == top) { top = holes.back().first; holes.pop_back(); }
+    }
+    float *ptr(size_t off) const { return measuring ? nullptr : reinterpret_cast<float *>(base + off); }
 };
 
 struct KTimeRec { hipEvent_t a, b; double flops; };
@@ -64,6 +93,11 @@ struct pmp_ctx {
     int chunk = 4096;   // blocks per pass: the 16x16-resolution layers need >= 4096 tiles to fill 256 CUs x 3 workgroups evenly (+2.5 % over 1024)
     int precision = 2;                     // 0: fp32 MFMA, 1: bf16x6 split, 2: f16x3 split (default; both splits fp32-equivalent)
     std::string err;
+    // f16x3 range guard (include/pmp.h, pmp_set_saturation_policy): device word raised by every kernel that clamps a stored activation
+    unsigned *d_sat = nullptr;
+    int sat_policy = PMP_SAT_RERUN;
+    int sat_seen = 0;                      // sticky: some inference call since pmp_clear_saturation saturated
+    int64_t sat_reruns = 0;                // calls re-run on the bf16x6 datapath
     std::map<int, pmp::NetWeights> nets;  // key = net_id * 100 + qp
     pmp::Arena arena;
     pmp::DevBuf ws;                        // activation workspace
@@ -90,7 +124,6 @@ int forward_q(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, con
               int n, float *qt);
 int forward_msbd(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, const uint8_t *bu, const uint8_t *bv,
                  const float *qt, int n, float *bt, float *dire);
-size_t workspace_floats_per_block(bool luma);
 
 // timing hooks used by nets.cpp
 struct KScope {

@@ -43,6 +43,7 @@ struct ConvX6Args {
     int relu, pool;
     unsigned long long *dbg;   // diagnostic builds only: 8 stamps per workgroup (nullptr otherwise)
     float out_scale;           // f16x3 only: 1/S of the power-of-two weight scaling (conv_f16x3.hip)
+    unsigned *sat;             // f16x3 only: sticky flag raised when a stored activation exceeded the fp16 range (may be nullptr)
 };
 hipError_t launch_conv_x6(hipStream_t s, const ConvX6Args &a);
 hipError_t launch_f32_to_split3(hipStream_t s, const float *x, unsigned short *out, size_t n, size_t plane_stride);
@@ -50,7 +51,7 @@ hipError_t launch_split3_to_f32(hipStream_t s, const unsigned short *x, float *o
 // Same operation on "split-2" activations (two fp16 planes) with three fp16 MFMA products per term (conv_f16x3.hip).
 // Weights packed [K-step][2 splits][Cout/16][64 lanes][8 fp16], pre-multiplied by 1/out_scale.
 hipError_t launch_conv_h2(hipStream_t s, const ConvX6Args &a);
-hipError_t launch_f32_to_split2(hipStream_t s, const float *x, unsigned short *out, size_t n, size_t plane_stride);
+hipError_t launch_f32_to_split2(hipStream_t s, const float *x, unsigned short *out, size_t n, size_t plane_stride, unsigned *sat = nullptr);
 hipError_t launch_split2_to_f32(hipStream_t s, const unsigned short *x, float *out, size_t n, size_t plane_stride);
 
 // ------------------------------------------------------------------------------------------------ stems
@@ -68,6 +69,7 @@ struct StemArgs {
     unsigned short *out_s3; size_t s3_stride;   // if out_s3 != nullptr the 32 channels are written as split planes ...
     int fmt;                                    // ... of format 1 (three bf16) or 2 (two fp16), see split3.h
     const unsigned short *wh; float out_scale;  // fmt 2: fp16 fragment stream (pack_stem_h2) and 1/scale -> the MFMA stem
+    unsigned *sat;                              // fmt 2: saturation flag (see ConvX6Args)
 };
 hipError_t launch_stem(hipStream_t s, bool luma, bool msbd, const StemArgs &a);
 
@@ -96,17 +98,18 @@ hipError_t launch_head(hipStream_t s, const HeadArgs &a);
 
 // x5 [N][2][16][16][16] -> cat[x5, up2(mp2), up4(mp4), up8(mp8)] [N][8][16][16][16]  (Model_QBD.py:84-87)
 hipError_t launch_multipool_concat(hipStream_t s, const float *x5, float *x6, int N, unsigned short *x6_s3 = nullptr,
-                                   size_t s3_stride = 0, int fmt = 1);
+                                   size_t s3_stride = 0, int fmt = 1, unsigned *sat = nullptr);
 
 // Attention trunk input (Model_QBD.py:140, :147): [N][1][S][S][16] with ch0 = up(q) (S/8 nearest), ch1 = bt[n][layer],
 // ch2 = dire[n][layer] (both 16x16, nearest-upsampled to S), channels 3..15 zero.
 hipError_t launch_att_input(hipStream_t s, const float *q, const float *bt, const float *dire, int layer, float *out,
-                            int N, int S, unsigned short *out_s3 = nullptr, size_t s3_stride = 0, int fmt = 1);
+                            int N, int S, unsigned short *out_s3 = nullptr, size_t s3_stride = 0, int fmt = 1, unsigned *sat = nullptr);
 
 // ------------------------------------------------------------------------------------------------ post-processing
 // eli_structual_error + Map_to_Partition, one wavefront per block.  qt raw logits [N][64]; bt, dire [N][3][256].
+// record_stride != 0: the four outputs are fields of one packed record per block (bytes between blocks), else dense arrays.
 hipError_t launch_postprocess(hipStream_t s, const float *qt, const float *bt, const float *dire, int64_t N,
-                              int chroma_factor, uint8_t *hor, uint8_t *ver, uint8_t *qt_u8, int8_t *dire_i8);
+                              int chroma_factor, uint8_t *hor, uint8_t *ver, uint8_t *qt_u8, int8_t *dire_i8, int record_stride = 0);
 
 // Block cutter (Inference_QBD.py:104-149).
 hipError_t launch_cut_blocks(hipStream_t s, const void *y, const void *u, const void *v, int F, int H, int W,

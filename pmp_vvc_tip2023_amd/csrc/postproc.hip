@@ -252,7 +252,8 @@ __device__ __forceinline__ void expand(Search &s)
 __global__ __launch_bounds__(256) void postprocess_kernel(const float *__restrict__ qt, const float *__restrict__ bt,
                                                           const float *__restrict__ dire, int64_t N, int cf,
                                                           uint8_t *__restrict__ hor_o, uint8_t *__restrict__ ver_o,
-                                                          uint8_t *__restrict__ qt_o, int8_t *__restrict__ dire_o)
+                                                          uint8_t *__restrict__ qt_o, int8_t *__restrict__ dire_o,
+                                                          int s_edge, int s_qt, int s_dire)   // bytes between consecutive blocks
 {
     __shared__ float valb_all[4][256], vald_all[4][256];
     __shared__ uint32_t horw[64], verw[64];
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(256) void postprocess_kernel(const float *__restric
     }
     // nearest x2 (Metrics.py:635): lane l holds the 8x8 value at (l>>3, l&7)
     const int qt8 = rlane(m, 0) * 0 + __shfl(m, ((lane >> 4) << 2) + ((lane & 7) >> 1));
-    if (wv == 0) qt_o[b * 64 + lane] = (uint8_t)qt8;
+    if (wv == 0) qt_o[b * s_qt + lane] = (uint8_t)qt8;
 
     // ---- Map_to_Partition.__init__ (Map2Partition.py:100-122)
     Search s;
@@ -377,8 +378,8 @@ __global__ __launch_bounds__(256) void postprocess_kernel(const float *__restric
     }
     __syncthreads();
     if (wv == 0) {
-        reinterpret_cast<uint32_t *>(hor_o + b * 256)[lane] = horw[lane];
-        reinterpret_cast<uint32_t *>(ver_o + b * 256)[lane] = verw[lane];
+        reinterpret_cast<uint32_t *>(hor_o + b * s_edge)[lane] = horw[lane];
+        reinterpret_cast<uint32_t *>(ver_o + b * s_edge)[lane] = verw[lane];
     }
     // a lane's four cells (row lane>>2, columns 4*(lane&3)..+3) lie in one quadrant: its owner holds their directions
     const bool whole = rlane(qt8, 0) == 0;   // the block is one 64x64 leaf: wave 0 searched it
@@ -388,17 +389,19 @@ __global__ __launch_bounds__(256) void postprocess_kernel(const float *__restric
         for (int k3 = 0; k3 < 3; ++k3) {
             const uint32_t pk = (uint32_t)(uint8_t)outd[k3][0] | ((uint32_t)(uint8_t)outd[k3][1] << 8) |
                                 ((uint32_t)(uint8_t)outd[k3][2] << 16) | ((uint32_t)(uint8_t)outd[k3][3] << 24);
-            reinterpret_cast<uint32_t *>(dire_o + (b * 3 + k3) * 256)[lane] = pk;
+            reinterpret_cast<uint32_t *>(dire_o + b * s_dire + k3 * 256)[lane] = pk;
         }
     }
 }
 
 hipError_t launch_postprocess(hipStream_t st, const float *qt, const float *bt, const float *dire, int64_t N,
-                              int chroma_factor, uint8_t *hor, uint8_t *ver, uint8_t *qt_u8, int8_t *dire_i8)
+                              int chroma_factor, uint8_t *hor, uint8_t *ver, uint8_t *qt_u8, int8_t *dire_i8, int record_stride)
 {
     if (N <= 0) return hipSuccess;
+    // four dense arrays (strides 256 / 256 / 64 / 768 bytes per block), or one packed record per block (include/pmp.h)
+    const int se = record_stride ? record_stride : 256, sq = record_stride ? record_stride : 64, sd = record_stride ? record_stride : 768;
     hipLaunchKernelGGL(postprocess_kernel, dim3((unsigned)N), dim3(256), 0, st, qt, bt, dire, N, chroma_factor, hor, ver,
-                       qt_u8, dire_i8);
+                       qt_u8, dire_i8, se, sq, sd);
     return hipGetLastError();
 }
 

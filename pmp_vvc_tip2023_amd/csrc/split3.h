@@ -60,6 +60,18 @@ __device__ __forceinline__ void split2(float v, _Float16 &a, _Float16 &b)
     b = (_Float16)(v - (float)a);   // v - a is exact in fp32; b keeps its leading 11 bits
 }
 
+// Saturation tracking (pmp_get_saturation, include/pmp.h): every kernel that writes split-2 planes keeps the largest |value|
+// it stores and raises the context's sticky flag when the clamp above fired for any of them.
+__device__ __forceinline__ float sat_amax4(float m, f32x4 v)
+{
+    return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+
+__device__ __forceinline__ void sat_report(unsigned *flag, float amax)
+{
+    if (flag && amax > 65504.f) atomicOr(flag, 1u);
+}
+
 __device__ __forceinline__ f32x4 load_split2_4(const unsigned short *p, size_t plane_stride)
 {
     const f16x4 a = *reinterpret_cast<const f16x4 *>(p), b = *reinterpret_cast<const f16x4 *>(p + plane_stride);
@@ -140,10 +152,11 @@ struct ActOut {
     unsigned short *s3;   // first split plane (format `fmt`), or nullptr for fp32 output
     size_t stride;
     int fmt;
+    unsigned *sat;        // split-2 only: the context's saturation flag (may be nullptr)
     __device__ __forceinline__ void store4(size_t elem, f32x4 v) const
     {
         if (!s3) *reinterpret_cast<f32x4 *>(f32 + elem) = v;
-        else if (fmt == FMT_H2) store_split2_4(s3 + elem, stride, v);
+        else if (fmt == FMT_H2) { sat_report(sat, sat_amax4(0.f, v)); store_split2_4(s3 + elem, stride, v); }
         else store_split4(s3 + elem, stride, v);
     }
 };

@@ -65,6 +65,9 @@ class Engine:
     def set_chunk(self, blocks):
         self._ck(self.lib.pmp_set_chunk(self.h, int(blocks)))
 
+    def workspace_bytes(self):
+        return int(self.lib.pmp_get_workspace_bytes(self.h))
+
     def set_precision(self, mode):
         """'f16x3' (default; 2-term fp16 split, 3 MFMA products), 'bf16x6' (3-term bf16 split, 6 products) - both
         fp32-equivalent - or 'fp32' (exact fp32 MFMA)."""
@@ -72,6 +75,21 @@ class Engine:
 
     def get_precision(self):
         return {0: "fp32", 1: "bf16x6", 2: "f16x3"}[self.lib.pmp_get_precision(self.h)]
+
+    def set_saturation_policy(self, policy):
+        """f16x3 range guard (include/pmp.h): 'rerun' (default: a call whose activations left the fp16 range is run again on
+        bf16x6), 'error' (PMP_E_RANGE instead) or 'ignore' (no check, fully asynchronous device calls)."""
+        self._ck(self.lib.pmp_set_saturation_policy(self.h, {"rerun": 0, "error": 1, "ignore": 2}[policy]))
+
+    def saturated(self):
+        """True if any inference call since clear_saturation() drove an f16x3 activation beyond +-65504."""
+        return bool(self._ck(self.lib.pmp_get_saturation(self.h)))
+
+    def saturation_reruns(self):
+        return int(self.lib.pmp_get_saturation_reruns(self.h))
+
+    def clear_saturation(self):
+        self._ck(self.lib.pmp_clear_saturation(self.h))
 
     def synchronize(self):
         self._ck(self.lib.pmp_synchronize(self.h))
@@ -181,6 +199,13 @@ class Engine:
     def infer_postprocess_device(self, comp, qp, d_by, d_bu, d_bv, n, d_hor, d_ver, d_q8, d_d8, d_qt=None, d_bt=None, d_dire=None):
         self._ck(self.lib.pmp_infer_postprocess_device(self.h, COMP_ID[comp], int(qp), d_by, d_bu, d_bv, int(n), d_hor, d_ver, d_q8,
                                                        d_d8, d_qt, d_bt, d_dire))
+
+    def infer_postprocess_records_device(self, comp, qp, d_by, d_bu, d_bv, n, d_rec):
+        """Blocks in, one packed 1344-byte record per block out (hor | ver | qt | dire): what the multi-GPU gather moves."""
+        self._ck(self.lib.pmp_infer_postprocess_records_device(self.h, COMP_ID[comp], int(qp), d_by, d_bu, d_bv, int(n), d_rec))
+
+    def postprocess_records_device(self, comp, d_qt, d_bt, d_dire, n, d_rec):
+        self._ck(self.lib.pmp_postprocess_records_device(self.h, COMP_ID[comp], d_qt, d_bt, d_dire, int(n), d_rec))
 
     def cut_blocks_device(self, d_y, d_u, d_v, F, H, Wd, bitdepth, d_by, d_bu, d_bv):
         self._ck(self.lib.pmp_cut_blocks_device(self.h, d_y, d_u, d_v, int(F), int(H), int(Wd), int(bitdepth), d_by, d_bu, d_bv))

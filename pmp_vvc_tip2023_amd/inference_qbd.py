@@ -75,20 +75,28 @@ def parse_seq_cfg(path):
     return seq_path, is10bit
 
 
-def import_yuv420(file_path, width, height, frm_num, SubSampleRatio=1, is10bit=False):
-    """Inference_QBD.py:78-102: every SubSampleRatio-th frame of a planar 4:2:0 file -> y[F,H,W], u,v[F,H/2,W/2]."""
+def import_yuv420(file_path, width, height, frm_num, SubSampleRatio=1, is10bit=False, frames=None):
+    """Inference_QBD.py:78-102: every SubSampleRatio-th frame of a planar 4:2:0 file -> y[F,H,W], u,v[F,H/2,W/2].
+    frames=(k0, k1) reads only the sub-sampled frames k0 <= k < k1 (a rank's shard: nothing else is touched on disk)."""
     pix = width * height
     sub = (frm_num + SubSampleRatio - 1) // SubSampleRatio
+    k0, k1 = (0, sub) if frames is None else (max(0, int(frames[0])), min(sub, int(frames[1])))
+    nf = max(0, k1 - k0)
     dt = np.uint16 if is10bit else np.uint8
-    y = np.zeros((sub, height, width), dt); u = np.zeros((sub, height // 2, width // 2), dt); v = np.zeros_like(u)
+    y = np.zeros((nf, height, width), dt); u = np.zeros((nf, height // 2, width // 2), dt); v = np.zeros_like(u)
     with open(file_path, "rb") as fp:
-        for i in range(0, frm_num, SubSampleRatio):
+        for k in range(k0, k1):
+            i = k * SubSampleRatio
             fp.seek(i * pix * 3 if is10bit else i * pix * 3 // 2, 0)
-            k = i // SubSampleRatio
-            y[k] = np.fromfile(fp, dtype=dt, count=pix).reshape(height, width)
-            u[k] = np.fromfile(fp, dtype=dt, count=pix // 4).reshape(height // 2, width // 2)
-            v[k] = np.fromfile(fp, dtype=dt, count=pix // 4).reshape(height // 2, width // 2)
+            y[k - k0] = np.fromfile(fp, dtype=dt, count=pix).reshape(height, width)
+            u[k - k0] = np.fromfile(fp, dtype=dt, count=pix // 4).reshape(height // 2, width // 2)
+            v[k - k0] = np.fromfile(fp, dtype=dt, count=pix // 4).reshape(height // 2, width // 2)
     return y, u, v
+
+
+def shard_frames(lo, hi, per_frame):
+    """Sub-sampled frames [f0, f1) that hold blocks lo <= b < hi (per_frame blocks each, frame-major order)."""
+    return lo // per_frame, (hi + per_frame - 1) // per_frame
 
 
 def strip_yuv_suffix(name):
@@ -117,6 +125,8 @@ def build_parser():
     p.add_argument("--allowSyntheticMTT", action="store_true",
                    help="run the MTT nets on the documented SYNTHETIC weights when a <Comp>_BD_<qp> model file is missing (the "
                         "reference checkout ships none); without this flag a missing model file is an error, as in the reference")
+    p.add_argument("--precision", default="f16x3", choices=["f16x3", "bf16x6", "fp32"],
+                   help="convolution datapath (all fp32-equivalent, include/pmp.h): f16x3 is fastest and range-guarded")
     p.add_argument("--hostBlocks", action="store_true",
                    help="keep the cut blocks in host memory and upload them for every (component, QP) pass, as the reference "
                         "does; default: frames are uploaded once, cut on the GPU and the blocks stay device-resident")
@@ -146,19 +156,17 @@ class DeviceBlocks:
         del ty, tu, tv
         self.by, self.bu, self.bv = self.by[lo:hi], self.bu[lo:hi], self.bv[lo:hi]   # leading-dimension slices: still contiguous
         self.n = hi - lo
-        self.hor = torch.empty((self.n, 16, 16), dtype=torch.uint8, device=dev)
-        self.ver = torch.empty_like(self.hor)
-        self.q8 = torch.empty((self.n, 8, 8), dtype=torch.uint8, device=dev)
-        self.d8 = torch.empty((self.n, 3, 16, 16), dtype=torch.int8, device=dev)
         torch.cuda.synchronize(dev)
 
-    def infer_postprocess(self, comp, qp):
+    def infer_postprocess_records(self, comp, qp):
+        """One pass; returns the shard's packed records u8[n, 1344] as a DEVICE tensor (a fresh one per pass: the previous
+        pass's records may still be in flight to the writer)."""
         chroma = comp == "Chroma"
-        self.eng.infer_postprocess_device(comp, qp, self.by.data_ptr(), self.bu.data_ptr() if chroma else None,
-                                          self.bv.data_ptr() if chroma else None, self.n, self.hor.data_ptr(), self.ver.data_ptr(),
-                                          self.q8.data_ptr(), self.d8.data_ptr())
-        self.eng.synchronize()
-        return tuple(t.cpu().numpy() for t in (self.hor, self.ver, self.q8, self.d8))
+        rec = self.torch.empty((self.n, parallel.RECORD), dtype=self.torch.uint8, device=self.dev)
+        self.eng.infer_postprocess_records_device(comp, qp, self.by.data_ptr(), self.bu.data_ptr() if chroma else None,
+                                                  self.bv.data_ptr() if chroma else None, self.n, rec.data_ptr())
+        self.eng.synchronize()      # the library runs on its own stream; the gather (torch's stream) must see finished records
+        return rec
 
 
 def _emit(rec, save_path, frames, height, width, binary):
@@ -195,6 +203,7 @@ def inference_VVC_seqs(args):
     # ragged chunks are bit-identical to one pass); small passes only leave most of an MI355X idle, so it is ignored unless
     # --strictBatch asks for it (clamped to the library's 4096-block pass; the reference accepts any value)
     eng.set_chunk(min(max(1, args.batchSize), 4096) if args.strictBatch else 4096)
+    eng.set_precision(args.precision)
     device = None
     if world > 1:
         import torch
@@ -243,24 +252,22 @@ def inference_VVC_seqs(args):
         seq_path = _resolve(seq_path, args.inputDir)
         if rank == 0:
             print(seq_name, flush=True)
-        # ---- load input blocks: every rank cuts only the frames of its own block range
+        # ---- load input blocks: every rank reads and cuts only the frames that hold its own block range
         t0 = time.time()
-        y, u, v = import_yuv420(seq_path, width, height, numfrm, args.ssRatio, is10bit)
         per_frame = (width // 64) * (height // 64)
         n_total = per_frame * sub_numfrm
         lo, hi = parallel.shard_bounds(n_total, rank, world)
         dblk = None
+        by = np.zeros((0, 68, 68), np.uint8); bu = np.zeros((0, 34, 34), np.uint8); bv = np.zeros((0, 34, 34), np.uint8)
         if hi > lo and per_frame:
-            f0, f1 = lo // per_frame, (hi + per_frame - 1) // per_frame
+            f0, f1 = shard_frames(lo, hi, per_frame)
+            y, u, v = import_yuv420(seq_path, width, height, numfrm, args.ssRatio, is10bit, frames=(f0, f1))
             if torch_dev is not None:   # frames go up once, are cut on the GPU and the blocks never leave it
-                dblk = DeviceBlocks(eng, torch_dev, y[f0:f1], u[f0:f1], v[f0:f1], 10 if is10bit else 8,
-                                    lo - f0 * per_frame, hi - f0 * per_frame)
-                by = bu = bv = None
+                dblk = DeviceBlocks(eng, torch_dev, y, u, v, 10 if is10bit else 8, lo - f0 * per_frame, hi - f0 * per_frame)
             else:
-                by, bu, bv = eng.output_block_yuv(y[f0:f1], u[f0:f1], v[f0:f1], 10 if is10bit else 8)
+                by, bu, bv = eng.output_block_yuv(y, u, v, 10 if is10bit else 8)
                 by, bu, bv = (a[lo - f0 * per_frame:hi - f0 * per_frame] for a in (by, bu, bv))
-        else:
-            by = np.zeros((0, 68, 68), np.uint8); bu = np.zeros((0, 34, 34), np.uint8); bv = np.zeros((0, 34, 34), np.uint8)
+            del y, u, v
         seqs_block_time[si] = time.time() - t0
 
         for comp in comps:
@@ -268,10 +275,17 @@ def inference_VVC_seqs(args):
             for qp in qps:
                 qi = (qp - 22) // 5 if qp in QPS else 0
                 t0 = time.time()
-                hor, ver, q8, d8 = dblk.infer_postprocess(comp, qp) if dblk is not None else eng.infer_postprocess(comp, qp, by, bu, bv)
+                reruns = eng.saturation_reruns()
+                if dblk is not None:     # records stay on the device until rank 0 has them all
+                    local = dblk.infer_postprocess_records(comp, qp)
+                else:
+                    local = parallel.pack_records(*eng.infer_postprocess(comp, qp, by, bu, bv))
                 seqs_net_time[si, qi, comp_id] = time.time() - t0
+                if eng.saturation_reruns() != reruns:   # f16x3 range guard (include/pmp.h): results are right, the pass cost 3x
+                    print("WARNING: rank %d: %s %s QP%d drove an activation beyond the fp16 range of the f16x3 datapath; the pass was "
+                          "re-run on bf16x6 (consider --precision bf16x6 for this model)" % (rank, seq_name, comp, qp), file=sys.stderr, flush=True)
                 t0 = time.time()
-                rec = parallel.gather_records(parallel.pack_records(hor, ver, q8, d8), n_total, device)
+                rec = parallel.gather_records(local, n_total, device)
                 if rank == 0:
                     # text emission (645 k lines per 1080p frame and file) runs on writer threads - the C writer releases
                     # the GIL - so it overlaps the next (component, QP) pass instead of serialising rank 0

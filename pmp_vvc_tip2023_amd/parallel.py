@@ -67,25 +67,38 @@ def init_process_group(device=None):
 def gather_records(local_rec, n_total, device=None):
     """Gather every rank's u8[n_r, 1344] records (rank order = block order) to rank 0.
 
-    Returns u8[n_total, 1344] on rank 0 and None elsewhere.  Shards are padded to the largest shard so the
-    collective has equal counts on every rank (RCCL gather / all-gather style); device tensors are used with the
-    nccl backend, CPU tensors with gloo.
+    local_rec is a numpy array or a torch tensor; a CUDA tensor (what pmp_infer_postprocess_records_device wrote) is
+    gathered as it is over RCCL - device to device across xGMI, no host bounce - and rank 0 copies the concatenation to the
+    host once, for the file writer.  Returns u8[n_total, 1344] (numpy) on rank 0 and None elsewhere.  Shards are padded to
+    the largest shard so the collective has equal counts on every rank; gloo (CPU hosts, tests) moves CPU tensors.
     """
     import torch
     import torch.distributed as dist
+    is_tensor = isinstance(local_rec, torch.Tensor)
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        return np.ascontiguousarray(local_rec)
+        return local_rec.cpu().numpy() if is_tensor else np.ascontiguousarray(local_rec)
     rank, world = dist.get_rank(), dist.get_world_size()
     counts = shard_counts(n_total, world)
     if local_rec.shape[0] != counts[rank]:
         raise ValueError("gather_records: rank %d holds %d records, shard is %d" % (rank, local_rec.shape[0], counts[rank]))
     cap = max(max(counts), 1)
-    dev = device if dist.get_backend() == "nccl" else torch.device("cpu")
-    buf = torch.zeros((cap, RECORD), dtype=torch.uint8, device=dev)
-    if counts[rank]:
-        buf[:counts[rank]] = torch.from_numpy(np.ascontiguousarray(local_rec)).to(dev)
-    out = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
-    dist.gather(buf, out, dst=0)
+    nccl = dist.get_backend() == "nccl"
+    if nccl:
+        dev = local_rec.device if (is_tensor and local_rec.is_cuda) else device
+    else:
+        dev = torch.device("cpu")
+    src = local_rec if is_tensor else torch.from_numpy(np.ascontiguousarray(local_rec))
+    src = src.reshape(-1, RECORD)
+    if src.shape[0] == cap and src.device == dev and src.is_contiguous():
+        buf = src                                              # full shard already where the collective needs it
+    else:
+        buf = torch.zeros((cap, RECORD), dtype=torch.uint8, device=dev)
+        if counts[rank]:
+            buf[:counts[rank]] = src.to(dev)
+    big = torch.empty((world * cap, RECORD), dtype=torch.uint8, device=dev) if rank == 0 else None
+    dist.gather(buf, list(big.split(cap)) if rank == 0 else None, dst=0)   # the views are the receive slots: no copy after
     if rank != 0:
         return None
-    return np.concatenate([o[:c].cpu().numpy() for o, c in zip(out, counts)], 0)
+    if all(c == cap for c in counts):                          # equal shards: the receive buffer IS the result
+        return big.cpu().numpy()
+    return torch.cat([big[r * cap:r * cap + c] for r, c in enumerate(counts)], 0).cpu().numpy()

@@ -102,3 +102,48 @@ def test_missing_mtt_weights_are_an_error_unless_asked_for(tmp_path):
 
 def test_time_sta_columns_follow_the_component_not_the_flag_order():
     assert D.COMP_COLUMN == {"Luma": 0, "Chroma": 1}
+
+
+def test_rank_reads_only_its_frames(tmp_path, monkeypatch):
+    """host I/O is the expected 8-GPU limiter, so a rank must read only the frames that hold its block range.
+    np.fromfile is wrapped to record every read; two ranks over a 5-frame sequence touch disjoint frame sets (one shared
+    frame where the block boundary falls inside it) and together every frame."""
+    from pmp_vvc_tip2023_amd import parallel
+    w, h, fr = 192, 128, 5                                     # 3 x 2 blocks per frame
+    rng = np.random.default_rng(9)
+    y = rng.integers(0, 256, (fr, h, w), dtype=np.uint8); u = rng.integers(0, 256, (fr, h // 2, w // 2), dtype=np.uint8)
+    v = rng.integers(0, 256, (fr, h // 2, w // 2), dtype=np.uint8)
+    p = tmp_path / "s.yuv"
+    with open(p, "wb") as f:
+        for i in range(fr):
+            f.write(y[i].tobytes()); f.write(u[i].tobytes()); f.write(v[i].tobytes())
+    reads = []
+    real = np.fromfile
+
+    def spy(fp, dtype=np.uint8, count=-1, **kw):
+        reads.append((fp.tell(), count))
+        return real(fp, dtype=dtype, count=count, **kw)
+    monkeypatch.setattr(D.np, "fromfile", spy)
+    per_frame, n_total = 6, 6 * fr
+    frame_bytes = w * h * 3 // 2
+    touched = []
+    for rank in range(2):
+        reads.clear()
+        lo, hi = parallel.shard_bounds(n_total, rank, 2)
+        f0, f1 = D.shard_frames(lo, hi, per_frame)
+        yy, uu, vv = D.import_yuv420(str(p), w, h, fr, 1, False, frames=(f0, f1))
+        assert np.array_equal(yy, y[f0:f1]) and np.array_equal(uu, u[f0:f1]) and np.array_equal(vv, v[f0:f1])
+        frames_read = sorted({off // frame_bytes for off, _ in reads})
+        assert frames_read == list(range(f0, f1)) and len(reads) == 3 * (f1 - f0)
+        touched.append(set(frames_read))
+    assert touched[0] == {0, 1, 2} and touched[1] == {2, 3, 4}   # 15 blocks each: the boundary falls inside frame 2
+    # temporal sub-sampling: sub-frame k is file frame k * ratio
+    reads.clear()
+    yy, _, _ = D.import_yuv420(str(p), w, h, fr, 2, False, frames=(1, 3))
+    assert np.array_equal(yy, y[[2, 4]]) and sorted({off // frame_bytes for off, _ in reads}) == [2, 4]
+    # out-of-range requests are clipped, an empty range reads nothing
+    reads.clear()
+    yy, _, _ = D.import_yuv420(str(p), w, h, fr, 1, False, frames=(4, 9))
+    assert yy.shape[0] == 1 and np.array_equal(yy[0], y[4])
+    reads.clear()
+    assert D.import_yuv420(str(p), w, h, fr, 1, False, frames=(3, 3))[0].shape[0] == 0 and not reads

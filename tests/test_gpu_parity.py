@@ -138,23 +138,63 @@ def test_caller_supplied_weights_and_errors(eng, g1):
         e2.close()
 
 
-def test_f16x3_saturates_instead_of_overflowing(g1):
-    """f16x3 carries activations as two fp16 terms: values beyond +-65504 must saturate when split, never turn into inf/NaN
-    (include/pmp.h, PMP_PRECISION_F16X3).  A stem scaled by 1e3 drives the trunk far beyond that range."""
-    from pmp_vvc_tip2023_amd import engine, synth
+def _range_stress_weights(K=256.0):
+    """Synthetic Luma MTT weights whose trunk activations are K x the usual ones while the logits are unchanged: the nets are
+    bias-free and ReLU is positively homogeneous, so scaling the stem (weights and biases) by a power of two K and the first
+    convolutions of the three branches (B1.0, B2.0, B3.0: left.0 and shortcut) by 1/K is exact in fp32 - the oracle gives the
+    logits of the unscaled net - but M1/M2 now carry values far beyond the fp16 range (Model_QBD.py:112-118, :136-151)."""
+    from pmp_vvc_tip2023_amd import synth
+    w = dict(synth.synth_msbd_weights("Luma", 22))
+    for k in ("conv_b1_1", "conv_b1_2", "conv_b1_3"):
+        w[k + ".weight"] = (w[k + ".weight"] * K).astype(np.float32)
+        w[k + ".bias"] = (w[k + ".bias"] * K).astype(np.float32)
+    for t in ("trunk_B1.0", "trunk_B2.0", "trunk_B3.0"):
+        for k in (".left.0.weight", ".shortcut.0.weight"):
+            w[t + k] = (w[t + k] / K).astype(np.float32)
+    return w
+
+
+def test_f16x3_range_guard(g1):
+    """f16x3 carries activations as two fp16 terms, so values beyond +-65504 would be clamped (include/pmp.h).  The guard must
+    (i) notice it, (ii) under the default policy return logits that are RIGHT (within 1e-3 of the oracle, by re-running the call
+    on bf16x6), (iii) return PMP_E_RANGE under PMP_SAT_ERROR, and (iv) under PMP_SAT_IGNORE still never produce inf/NaN."""
+    from oracle import nets_torch as O
+    from pmp_vvc_tip2023_amd import _lib, engine, weights as W
+    y = np.ascontiguousarray(g1["block_y"][:6])
+    w = _range_stress_weights()
+    wq, _ = W.load_net_weights("Luma_Q", 22)
+    oq, obt, odire = O.infer_qbd(wq, w, O.luma_input(y), True)
+    assert np.abs(obt).max() < 50                             # the logits themselves are ordinary
     e2 = engine.Engine(0, allow_synthetic_mtt=True)
     try:
         e2.set_precision("f16x3")
-        e2.load("Luma", 22)                                 # real QT net for the MTT net's second input
-        w = dict(synth.synth_msbd_weights("Luma", 22))
-        for k in ("conv_b1_1.weight", "conv_b1_2.weight", "conv_b1_3.weight"):
-            w[k] = (w[k] * 1e3).astype(np.float32)
+        e2.load("Luma", 22)                                    # real QT net; MTT net replaced below
+        assert not e2.saturated() and e2.saturation_reruns() == 0
         e2.load_pretrain_model("Luma_MSBD", 22, w)
-        qt, bt, dire = e2.inference_pre_QBD("Luma", 22, g1["block_y"][:4])
-        assert np.isfinite(qt).all() and np.isfinite(bt).all() and np.isfinite(dire).all()
-        e2.set_precision("fp32")                            # the exact path agrees that the values are huge, not broken
-        _, bt32, _ = e2.inference_pre_QBD("Luma", 22, g1["block_y"][:4])
-        assert np.isfinite(bt32).all() and np.abs(bt32).max() > 1e3
+        qt, bt, dire = e2.inference_pre_QBD("Luma", 22, y)     # default policy: re-run on bf16x6
+        assert e2.saturated() and e2.saturation_reruns() == 1
+        err = max(np.abs(qt - oq).max(), np.abs(bt - obt).max(), np.abs(dire - odire).max())
+        assert err < TOL, "range guard re-run is off by %g" % err
+        hor, ver, q8, d8, qt2, bt2, dire2 = e2.infer_postprocess("Luma", 22, y, want_logits=True)   # the fused entry point too
+        assert e2.saturation_reruns() == 2 and np.array_equal(bt2, bt) and np.array_equal(dire2, dire)
+        e2.set_saturation_policy("error")
+        with pytest.raises(_lib.PmpError) as ei:
+            e2.inference_pre_QBD("Luma", 22, y)
+        assert ei.value.code == -7
+        e2.set_saturation_policy("ignore")
+        e2.clear_saturation()
+        assert not e2.saturated()
+        q3, b3, d3 = e2.inference_pre_QBD("Luma", 22, y)
+        assert np.isfinite(q3).all() and np.isfinite(b3).all() and np.isfinite(d3).all()
+        assert e2.saturated()                                  # polled: the device word was raised
+        assert max(np.abs(b3 - obt).max(), np.abs(d3 - odire).max()) > TOL   # ... and clamped activations do change the logits
+        # the same weights on the other two datapaths need no guard
+        for prec in ("bf16x6", "fp32"):
+            e2.set_precision(prec)
+            e2.clear_saturation()
+            q4, b4, d4 = e2.inference_pre_QBD("Luma", 22, y)
+            assert max(np.abs(q4 - oq).max(), np.abs(b4 - obt).max(), np.abs(d4 - odire).max()) < TOL
+            assert not e2.saturated()
     finally:
         e2.close()
 
@@ -278,6 +318,8 @@ def test_config2_full_batch_properties(eng, oracle_lib):
         outs.append([t.cpu().numpy() for t in (hor, ver, q8, d8, qt, bt, dire)])
     for a, b in zip(outs[0], outs[1]):
         assert np.array_equal(a, b)
+    assert not eng.saturated() and eng.saturation_reruns() == 0   # configs[1] stays far inside the f16x3 range: no re-run
+    assert eng.workspace_bytes() <= {"f16x3": 2.75, "bf16x6": 4.1, "fp32": 2.75}[eng.get_precision()] * 2 ** 20 * n   # arena reuse
     hor, ver, q8, d8, qt, bt, dire = outs[0]
     h2, v2, q82, d82 = eng.post_process(qt, bt, dire, "Luma")
     assert np.array_equal(hor, h2) and np.array_equal(ver, v2) and np.array_equal(q8, q82) and np.array_equal(d8, d82)
@@ -463,3 +505,44 @@ def test_bench_json_contract(tmp_path):
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert d["parity"]["logit_max_abs_err"] < 1e-3 and d["parity"]["flag_mismatch_vs_oracle_postproc_of_device_logits"] == 0
     assert d["value"] > 50 * cb["value"]   # sanity: the GPU path is not the CPU path
+    assert rf["traffic_source"] is None or "pmc_traffic.json" in rf["traffic_source"]
+    e2e = d["e2e_host_buffers"]                 # the H2D/D2H-inclusive figure beside the device-resident one
+    assert e2e["unit"] == "CTU/s" and 0 < e2e["value"] <= d["value"] * 1.5 and e2e["h2d_bytes_per_step"] == 64 * 68 * 68
+    assert set(d["extra"]["luma_ctu_per_s_by_qp"]) == {"22", "27", "32", "37"} and d["extra"]["chroma_qp22_ctu_per_s"] > 0
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher starts two rank processes itself (fresh children, before the parent makes
+    a GPU call) and prints ONE line with n_gpus = 2 and twice the blocks.  Both ranks share the test box's single GPU, so the
+    collective runs over gloo here (PMP_DIST_BACKEND); on a multi-GPU node the same path gathers device tensors over RCCL."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PMP_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "32",
+                        "--cpu-sample", "0", "--no-extras"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["blocks_per_gpu"] == 32 and d["config"]["global_blocks"] == 64 and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["cpu_baseline"] is None
+
+
+def test_records_entry_point_equals_the_four_arrays(eng):
+    """pmp_infer_postprocess_records_device writes hor | ver | qt | dire of every block as one 1344-byte record: the same bytes
+    as the four dense arrays of pmp_infer_postprocess_device, packed (what the multi-GPU gather moves)."""
+    from pmp_vvc_tip2023_amd import parallel, synth
+    n = 37
+    y, u, v = synth.recipe_r_blocks(n, 5)
+    dev = torch.device("cuda:0")
+    d_y, d_u, d_v = (torch.from_numpy(a).to(dev) for a in (y, u, v))
+    for comp in ("Luma", "Chroma"):
+        eng.load(comp, 32)
+        rec = torch.zeros((n, 1344), dtype=torch.uint8, device=dev)
+        pu, pv = (d_u.data_ptr(), d_v.data_ptr()) if comp == "Chroma" else (None, None)
+        eng.infer_postprocess_records_device(comp, 32, d_y.data_ptr(), pu, pv, n, rec.data_ptr())
+        eng.synchronize()
+        hor, ver, q8, d8 = eng.infer_postprocess(comp, 32, y, u, v)
+        assert np.array_equal(rec.cpu().numpy(), parallel.pack_records(hor, ver, q8, d8))

@@ -75,3 +75,57 @@ def test_two_rank_gloo_gather_matches_single_process(tmp_path):
     logs = [p.communicate(timeout=180)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\\n".join(logs)
     assert open(out, "rb").read() == open(golden_path("g5_partitionmat_Luma.txt"), "rb").read()
+
+
+WORKER_T = textwrap.dedent('''
+    import os, sys
+    sys.path.insert(0, %(root)r)
+    import numpy as np, torch
+    from pmp_vvc_tip2023_amd import parallel
+    rank, world, _ = parallel.init_process_group(None)
+    for n_total in (5, 6, 1, 0):                       # unequal shards, equal shards, fewer records than ranks, none
+        allrec = (np.arange(n_total * parallel.RECORD, dtype=np.int64) %% 251).astype(np.uint8).reshape(n_total, parallel.RECORD)
+        lo, hi = parallel.shard_bounds(n_total, rank, world)
+        for as_tensor in (True, False):
+            local = torch.from_numpy(allrec[lo:hi].copy()) if as_tensor else allrec[lo:hi].copy()
+            got = parallel.gather_records(local, n_total)
+            if rank == 0:
+                assert isinstance(got, np.ndarray) and got.shape == (n_total, parallel.RECORD) and np.array_equal(got, allrec), n_total
+            else:
+                assert got is None
+    try:
+        parallel.gather_records(np.zeros((3, parallel.RECORD), np.uint8), 2)    # wrong shard size is refused on every rank
+        raise SystemExit("shard-size check missing")
+    except ValueError:
+        pass
+    import torch.distributed as dist
+    dist.barrier(); dist.destroy_process_group()
+''')
+
+
+def test_two_rank_gather_accepts_tensors_and_ragged_shards(tmp_path):
+    """gather_records takes what the device path hands it (a torch tensor of packed records) as well as numpy arrays; shards
+    may be unequal or empty.  On the GPU node the same code moves CUDA tensors over RCCL; here gloo moves CPU tensors."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "worker_t.py"
+    script.write_text(WORKER_T % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    logs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\\n".join(logs)
+
+
+def test_bench_self_launch_propagates_rank_failure():
+    """`python bench.py --gpus 2` starts its own rank processes; on a box without a GPU every rank refuses to run (there is no
+    CPU fallback) and the parent must exit non-zero without printing a result line."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_gpu_parity.py::test_bench_launches_its_own_ranks")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and not r.stdout.strip()
+    assert r.stderr.count("no CPU fallback") == 2          # both ranks were started and both refused
