@@ -189,12 +189,17 @@ def main():
                     help="conv datapath: 2-term fp16 split (3 MFMA products) or 3-term bf16 split (6 products), both "
                          "fp32-equivalent, or exact fp32 MFMA")
     ap.add_argument("--breakdown", action="store_true", help="extra pass with every kernel class timed (stderr)")
+    ap.add_argument("--lib", default=None, help="path of another build of libpmp_hip.so (same-box A/B timing, tools/lib_ab.py)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the side measurements after the timed region (host-buffer end-to-end rate, chroma, per-QP luma)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # no launcher: become one (before any GPU call)
         raise SystemExit(launch_ranks(args.gpus))
+    # stdout carries exactly ONE line, the JSON: whatever a library prints on fd 1 (gloo / RCCL banners) goes to stderr
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -218,7 +223,9 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from pmp_vvc_tip2023_amd import engine, synth
+    from pmp_vvc_tip2023_amd import _lib, engine, synth
+    if args.lib:
+        _lib.load(args.lib)
     eng = engine.Engine(local_rank, allow_synthetic_mtt=True)
     if args.chunk:
         eng.set_chunk(args.chunk)
@@ -342,7 +349,7 @@ def main():
             out["cpu_baseline"], out["parity"] = cpu_baseline(args.cpu_sample, 1, eng)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     eng.close()
     if dist:
         dist.destroy_process_group()

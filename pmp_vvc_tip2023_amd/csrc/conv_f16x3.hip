@@ -552,24 +552,29 @@ __device__ __forceinline__ void h2_epilogue(const ConvX6Args &a, f32x4 (&acc)[Wa
     // with its wave-uniform branches per cout group: the branches keep one group's stores ahead of the next group's conversions.)
     // All residual (then gate) fragments are requested before the first store: the weight, pixel and staging registers are
     // dead by now, and a load issued after a store to `out` would otherwise have to wait for it (possible aliasing).
+    // Residual loads and output stores move 16 bytes per lane: lane (xl, g) handles the 8 consecutive channels 8(g>>1).. of pixel
+    // (row m + (g&1), xl) - one v_permlane16_swap per register (gfx950) exchanges that form with the accumulator layout (4
+    // couts 4g.. of rows m and m+1).  Half the vector-memory instructions of 8-byte accesses: the epilogue is issue-bound.
+    const unsigned off0w = off0 - (unsigned)(g * 4) + (unsigned)(8 * (g >> 1)) + (unsigned)(g & 1) * row_el;
     if (a.res) {
-        f16x4 ra[RW][CW], rbv[RW][CW];
+        u32x4 ra[RW / 2][CW], rbv[RW / 2][CW];
 #pragma unroll
         for (int nt = 0; nt < CW; ++nt)
 #pragma unroll
-            for (int m = 0; m < RW; ++m) {
-                const unsigned off = off0 + (unsigned)m * row_el + (unsigned)nt * (unsigned)grp;
-                ra[m][nt] = *reinterpret_cast<const f16x4 *>(a.res + off);
-                rbv[m][nt] = *reinterpret_cast<const f16x4 *>(a.res + off + a.res_stride);
+            for (int m = 0; m < RW; m += 2) {
+                const unsigned off = off0w + (unsigned)m * row_el + (unsigned)nt * (unsigned)grp;
+                ra[m >> 1][nt] = *reinterpret_cast<const u32x4 *>(a.res + off);
+                rbv[m >> 1][nt] = *reinterpret_cast<const u32x4 *>(a.res + off + a.res_stride);
             }
 #pragma unroll
         for (int nt = 0; nt < CW; ++nt)
 #pragma unroll
-            for (int m = 0; m < RW; ++m) {
-                f32x4 v = acc[m][nt] * inv_scale;   // undo the power-of-two weight scaling (exact)
-                const f16x4 p = ra[m][nt], q = rbv[m][nt];
-                v.x += (float)p.x + (float)q.x; v.y += (float)p.y + (float)q.y; v.z += (float)p.z + (float)q.z; v.w += (float)p.w + (float)q.w;
-                acc[m][nt] = v;
+            for (int m = 0; m < RW; m += 2) {
+                u32x4 p = ra[m >> 1][nt], q = rbv[m >> 1][nt];
+                rows16_swap(p);
+                rows16_swap(q);
+                acc[m][nt] = acc[m][nt] * inv_scale + (h2_lo4(p) + h2_lo4(q));        // undo the power-of-two weight scaling (exact)
+                acc[m + 1][nt] = acc[m + 1][nt] * inv_scale + (h2_hi4(p) + h2_hi4(q));
             }
     } else {
 #pragma unroll
@@ -590,12 +595,22 @@ __device__ __forceinline__ void h2_epilogue(const ConvX6Args &a, f32x4 (&acc)[Wa
             acc[m][nt] = v;
         }
         if (!a.pool) {
+            if (a.out_f32) {
 #pragma unroll
-            for (int m = 0; m < RW; ++m) {
-                const unsigned off = off0 + (unsigned)m * row_el + (unsigned)nt * (unsigned)grp;
-                if (a.out_f32) *reinterpret_cast<f32x4 *>(a.out_f32 + off) = acc[m][nt];
-                else if ((ABL & 16) && a.N > 0) { f32x4 q = acc[m][nt]; _Float16 h0, h1; split2(q.x + q.y + q.z + q.w, h0, h1); if ((float)h0 + (float)h1 == 123.456f) a.out[off] = 1; }   // timing-only: the conversion work without the stores
-                else store_split2_4(a.out + off, a.out_stride, acc[m][nt]);
+                for (int m = 0; m < RW; ++m)
+                    *reinterpret_cast<f32x4 *>(a.out_f32 + off0 + (unsigned)m * row_el + (unsigned)nt * (unsigned)grp) = acc[m][nt];
+            } else {
+#pragma unroll
+                for (int m = 0; m < RW; m += 2) {
+                    const unsigned off = off0w + (unsigned)m * row_el + (unsigned)nt * (unsigned)grp;
+                    if ((ABL & 16) && a.N > 0) { f32x4 q = acc[m][nt] + acc[m + 1][nt]; _Float16 h0, h1; split2(q.x + q.y + q.z + q.w, h0, h1); if ((float)h0 + (float)h1 == 123.456f) a.out[off] = 1; continue; }   // timing-only: conversion work without the stores
+                    u32x4 p, q;
+                    split2_rows(acc[m][nt], acc[m + 1][nt], p, q);
+                    rows16_swap(p);
+                    rows16_swap(q);
+                    *reinterpret_cast<u32x4 *>(a.out + off) = p;
+                    *reinterpret_cast<u32x4 *>(a.out + off + a.out_stride) = q;
+                }
             }
         } else {
             const int Ho = H >> 1, Wo = W >> 1;

@@ -89,6 +89,43 @@ __device__ __forceinline__ void store_split2_4(unsigned short *p, size_t plane_s
     *reinterpret_cast<f16x4 *>(p + plane_stride) = b;
 }
 
+// ---- 16-byte epilogue accesses of the split-2 kernels.  An MFMA accumulator leaves lane (xl, g) with the 4 couts 4g.. of one
+// pixel; two rows (m, m+1) of it are 2 x 2 packed dwords per plane.  v_permlane16_swap_b32 (gfx950) swaps the odd 16-lane rows
+// of one register with the even rows of another, which turns {row m, row m+1} x {couts 4g..} into the 8 consecutive channels
+// 8(g>>1).. of row m + (g&1): one 16-byte access per lane instead of two 8-byte ones.  The exchange is its own inverse.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void rows16_swap(u32x4 &v)   // (x, y) = row m half, (z, w) = row m+1 half  <->  16 contiguous bytes
+{
+    const u32x2 a = __builtin_amdgcn_permlane16_swap(v.x, v.z, false, false);
+    const u32x2 b = __builtin_amdgcn_permlane16_swap(v.y, v.w, false, false);
+    v.x = a.x; v.z = a.y; v.y = b.x; v.w = b.y;
+}
+
+__device__ __forceinline__ f32x4 h2_lo4(u32x4 v)   // the 4 fp16 values in (x, y) as floats
+{
+    const f16x4 h = __builtin_bit_cast(f16x4, (u32x2){v.x, v.y});
+    return (f32x4){(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+}
+
+__device__ __forceinline__ f32x4 h2_hi4(u32x4 v)
+{
+    const f16x4 h = __builtin_bit_cast(f16x4, (u32x2){v.z, v.w});
+    return (f32x4){(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+}
+
+// two rows of one cout group -> their high-term dwords p = (row m: x, y | row m+1: z, w) and low-term dwords q
+__device__ __forceinline__ void split2_rows(f32x4 r0, f32x4 r1, u32x4 &p, u32x4 &q)
+{
+    _Float16 a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3, d0, d1, d2, d3;
+    split2(r0.x, a0, b0); split2(r0.y, a1, b1); split2(r0.z, a2, b2); split2(r0.w, a3, b3);
+    split2(r1.x, c0, d0); split2(r1.y, c1, d1); split2(r1.z, c2, d2); split2(r1.w, c3, d3);
+    const u32x2 pa = __builtin_bit_cast(u32x2, (f16x4){a0, a1, a2, a3}), pc = __builtin_bit_cast(u32x2, (f16x4){c0, c1, c2, c3});
+    const u32x2 qb = __builtin_bit_cast(u32x2, (f16x4){b0, b1, b2, b3}), qd = __builtin_bit_cast(u32x2, (f16x4){d0, d1, d2, d3});
+    p = (u32x4){pa.x, pa.y, pc.x, pc.y};
+    q = (u32x4){qb.x, qb.y, qd.x, qd.y};
+}
+
 // same, with the streaming (non-temporal) hint: activations are written once and read by the NEXT launch, far beyond L2
 __device__ __forceinline__ void store_split2_4_nt(unsigned short *p, size_t plane_stride, f32x4 v)
 {

@@ -138,11 +138,12 @@ def test_caller_supplied_weights_and_errors(eng, g1):
         e2.close()
 
 
-def _range_stress_weights(K=256.0):
+def _range_stress_weights(K=2.0 ** 17):
     """Synthetic Luma MTT weights whose trunk activations are K x the usual ones while the logits are unchanged: the nets are
     bias-free and ReLU is positively homogeneous, so scaling the stem (weights and biases) by a power of two K and the first
     convolutions of the three branches (B1.0, B2.0, B3.0: left.0 and shortcut) by 1/K is exact in fp32 - the oracle gives the
-    logits of the unscaled net - but M1/M2 now carry values far beyond the fp16 range (Model_QBD.py:112-118, :136-151)."""
+    logits of the unscaled net - but M1/M2 now carry values far beyond the fp16 range (Model_QBD.py:112-118, :136-151): the
+    synthetic nets' activations are O(1..4), so K = 2^17 puts them at 2e5..5e5."""
     from pmp_vvc_tip2023_amd import synth
     w = dict(synth.synth_msbd_weights("Luma", 22))
     for k in ("conv_b1_1", "conv_b1_2", "conv_b1_3"):
