@@ -110,6 +110,10 @@ int pmp_clear_saturation(pmp_ctx *ctx);
  * Every tensor the net needs must be present with the reference's shape (else PMP_E_INVALID). */
 int pmp_load_weights(pmp_ctx *ctx, int net_id, int qp, const float *blob, const pmp_tensor_desc *descs,
                      int ndesc);
+/* The same from the product's weight container (<Comp>_{Q,BD}_<qp>.pmpw, pmp_vvc_tip2023_amd/weights.py; tools/convert_weights.py
+ * makes one from a reference .pkl): for hosts without Python, e.g. the in-process VTM hook (tools/vtm_build/pmp_hook.cpp).
+ * The manifest's net and QP must match the arguments. */
+int pmp_load_weights_file(pmp_ctx *ctx, int net_id, int qp, const char *path);
 int pmp_has_weights(const pmp_ctx *ctx, int net_id, int qp);
 
 /* ---- inference: inference_pre_QBD (Metrics.py:387-419).  block_u/block_v are ignored for PMP_LUMA. --- */
@@ -198,6 +202,10 @@ int pmp_debug_set_conv_variant(int variant);
  *      [K-step][2 splits][cout_pad/16][64 lanes][8] of fp16 bit patterns (h0, h1 with h0 + h1 ~= S*w) to out.
  *      Returns the number of uint16 elements of the stream (> cap: nothing written), or a negative error. ---- */
 int64_t pmp_debug_pack_f16x3(const float *w, int cout, int cin, int k, uint16_t *out, int64_t cap, int *scale_exp);
+
+/* ---- test hook (host only): parse a .pmpw container; reports its net id (-1 if unknown), QP, tensor count, payload floats
+ *      and the sum of all tensor elements. ---- */
+int pmp_debug_read_weights_file(const char *path, int *net_id, int *qp, int *ntensors, int64_t *nfloats, double *checksum);
 
 /* ---- measurement hook: one convolution layer on random data, both datapaths.  Runs conv KxK Cin->Cout (+ReLU) on
  *      n blocks of HxW with the fp32-MFMA kernel and with the context's split kernel (f16x3 or bf16x6; bf16x6 if the

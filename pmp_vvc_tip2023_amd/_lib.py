@@ -41,7 +41,9 @@ SIGNATURES = {
     "pmp_get_saturation_reruns": (_I64, [_VP]),
     "pmp_clear_saturation": (_I, [_VP]),
     "pmp_load_weights": (_I, [_VP, _I, _I, _VP, C.POINTER(TensorDesc), _I]),
+    "pmp_load_weights_file": (_I, [_VP, _I, _I, C.c_char_p]),
     "pmp_has_weights": (_I, [_VP, _I, _I]),
+    "pmp_debug_read_weights_file": (_I, [C.c_char_p, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I64), C.POINTER(C.c_double)]),
     "pmp_infer": (_I, [_VP, _I, _I, _VP, _VP, _VP, _I64, _VP, _VP, _VP]),
     "pmp_infer_device": (_I, [_VP, _I, _I, _VP, _VP, _VP, _I64, _VP, _VP, _VP]),
     "pmp_postprocess": (_I, [_VP, _I, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP]),

@@ -318,6 +318,26 @@ int pmp_load_weights(pmp_ctx *c, int net_id, int qp, const float *blob, const pm
     return load_net_weights(c, net_id, qp, blob, descs, ndesc);
 }
 
+int pmp_load_weights_file(pmp_ctx *c, int net_id, int qp, const char *path)
+{
+    CHECK_CTX(c);
+    WeightFile wf;
+    int rc = read_pmpw(path, wf);
+    if (rc != PMP_OK) return set_err(c, rc, global_err());
+    if (!wf.net.empty() && net_id_of(wf.net) != net_id)
+        return set_err(c, PMP_E_INVALID, std::string(path) + ": holds net " + wf.net + ", not the net asked for");
+    if (wf.qp >= 0 && wf.qp != qp) return set_err(c, PMP_E_INVALID, std::string(path) + ": holds QP " + std::to_string(wf.qp));
+    std::vector<pmp_tensor_desc> descs(wf.tensors.size());
+    for (size_t i = 0; i < wf.tensors.size(); ++i) {
+        descs[i].name = wf.tensors[i].name.c_str();
+        descs[i].ndim = wf.tensors[i].ndim;
+        for (int j = 0; j < 4; ++j) descs[i].shape[j] = wf.tensors[i].shape[j];
+        descs[i].offset = wf.tensors[i].offset;
+    }
+    if ((rc = sync(c)) != PMP_OK) return rc;
+    return load_net_weights(c, net_id, qp, wf.payload.data(), descs.data(), (int)descs.size());
+}
+
 int pmp_has_weights(const pmp_ctx *c, int net_id, int qp)
 {
     if (!c) return 0;

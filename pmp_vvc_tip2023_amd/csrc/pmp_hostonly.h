@@ -22,4 +22,11 @@ int h2_scale_exp(const float *w, size_t n);
 std::vector<unsigned short> pack_stem_h2(const float *w32, int cin, int k1, int scale_exp);
 std::vector<float> pack_plain(const float *w, int cout, int cin, int kh, int kw);
 
+
+// pmpw_file.cpp: the product's weight container (.pmpw)
+struct WeightTensor { std::string name; int ndim = 0; int shape[4] = {0, 0, 0, 0}; long long offset = 0; };
+struct WeightFile { std::string net; int qp = -1; std::vector<WeightTensor> tensors; std::vector<float> payload; };
+int read_pmpw(const char *path, WeightFile &wf);
+int net_id_of(const std::string &net);
+
 }  // namespace pmp

@@ -1,0 +1,178 @@
+// pmpw_file.cpp — reader of the product's weight container (.pmpw, written by pmp_vvc_tip2023_amd/weights.py):
+//
+//     "PMPW1\n" | u32 little-endian JSON length | JSON manifest | raw little-endian float32 payload
+//     manifest = {"net": "Luma_Q", "qp": 22, "source": "...", "tensors": [{"name": "...", "shape": [..], "offset": N}, ...]}
+//
+// so that a host without Python (the in-process VTM hook) can feed pmp_load_weights.  Counterpart of
+// load_pretrain_model (Inference_QBD.py:28-46).  Pure host code (no HIP): part of the sanitizer test library too.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "pmp_hostonly.h"
+
+namespace pmp {
+
+namespace {
+
+// Minimal scanner for the manifest's own schema (objects, arrays, strings without escapes beyond \" and \\, integers).
+struct Scan {
+    const char *p, *end;
+    void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p; }
+    bool lit(char c) { ws(); if (p < end && *p == c) { ++p; return true; } return false; }
+    bool str(std::string &out)
+    {
+        ws();
+        if (p >= end || *p != '"') return false;
+        ++p;
+        out.clear();
+        while (p < end && *p != '"') {
+            if (*p == '\\') { if (++p >= end) return false; }
+            out.push_back(*p++);
+        }
+        if (p >= end) return false;
+        ++p;
+        return true;
+    }
+    bool integer(long long &v)
+    {
+        ws();
+        char *e = nullptr;
+        if (p >= end || !((*p >= '0' && *p <= '9') || *p == '-')) return false;
+        v = strtoll(p, &e, 10);
+        if (e == p || e > end) return false;
+        p = e;
+        return true;
+    }
+    bool skip_value()   // any JSON value
+    {
+        ws();
+        if (p >= end) return false;
+        if (*p == '"') { std::string s; return str(s); }
+        if (*p == '{' || *p == '[') {
+            const char open = *p, close = open == '{' ? '}' : ']';
+            ++p;
+            if (lit(close)) return true;
+            for (;;) {
+                if (open == '{') { std::string k; if (!str(k) || !lit(':')) return false; }
+                if (!skip_value()) return false;
+                if (lit(',')) continue;
+                return lit(close);
+            }
+        }
+        while (p < end && *p != ',' && *p != '}' && *p != ']' && *p != ' ' && *p != '\n') ++p;   // number / true / false / null
+        return true;
+    }
+};
+
+}  // namespace
+
+int read_pmpw(const char *path, WeightFile &wf)
+{
+    wf = WeightFile();
+    if (!path) return set_err_global(PMP_E_INVALID, "pmp weights file: null path");
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return set_err_global(PMP_E_IO, std::string("cannot open ") + path);
+    std::vector<char> raw;
+    char buf[1 << 16];
+    size_t got;
+    while ((got = fread(buf, 1, sizeof(buf), fp)) > 0) raw.insert(raw.end(), buf, buf + got);
+    fclose(fp);
+    if (raw.size() < 10 || memcmp(raw.data(), "PMPW1\n", 6) != 0) return set_err_global(PMP_E_INVALID, std::string(path) + ": not a PMPW1 file");
+    uint32_t jl = 0;
+    for (int i = 0; i < 4; ++i) jl |= (uint32_t)(unsigned char)raw[6 + i] << (8 * i);
+    if ((size_t)jl > raw.size() - 10) return set_err_global(PMP_E_INVALID, std::string(path) + ": manifest length exceeds the file");
+    const size_t pay_off = 10 + (size_t)jl, nfl = (raw.size() - pay_off) / 4;
+    wf.payload.resize(nfl);
+    if (nfl) memcpy(wf.payload.data(), raw.data() + pay_off, nfl * 4);   // little-endian host (x86-64): raw copy
+
+    Scan s{raw.data() + 10, raw.data() + 10 + jl};
+    auto bad = [&](const char *what) { return set_err_global(PMP_E_INVALID, std::string(path) + ": manifest: " + what); };
+    if (!s.lit('{')) return bad("not an object");
+    bool have_tensors = false;
+    if (!s.lit('}')) {
+        for (;;) {
+            std::string key;
+            if (!s.str(key) || !s.lit(':')) return bad("bad key");
+            if (key == "net") { if (!s.str(wf.net)) return bad("net is not a string"); }
+            else if (key == "qp") { long long v; if (!s.integer(v)) return bad("qp is not an integer"); wf.qp = (int)v; }
+            else if (key == "tensors") {
+                have_tensors = true;
+                if (!s.lit('[')) return bad("tensors is not an array");
+                if (!s.lit(']')) {
+                    for (;;) {
+                        WeightTensor t;
+                        bool have_off = false;
+                        if (!s.lit('{')) return bad("tensor entry is not an object");
+                        for (;;) {
+                            std::string k;
+                            if (!s.str(k) || !s.lit(':')) return bad("bad tensor key");
+                            if (k == "name") { if (!s.str(t.name)) return bad("tensor name"); }
+                            else if (k == "offset") { long long v; if (!s.integer(v) || v < 0) return bad("tensor offset"); t.offset = v; have_off = true; }
+                            else if (k == "shape") {
+                                if (!s.lit('[')) return bad("tensor shape");
+                                if (!s.lit(']')) {
+                                    for (;;) {
+                                        long long v;
+                                        if (!s.integer(v) || v < 0 || v > (1 << 24) || t.ndim >= 4) return bad("tensor shape entry");
+                                        t.shape[t.ndim++] = (int)v;
+                                        if (s.lit(',')) continue;
+                                        if (!s.lit(']')) return bad("tensor shape end");
+                                        break;
+                                    }
+                                }
+                            } else if (!s.skip_value()) return bad("tensor value");
+                            if (s.lit(',')) continue;
+                            if (!s.lit('}')) return bad("tensor entry end");
+                            break;
+                        }
+                        long long cnt = 1;
+                        for (int i = 0; i < t.ndim; ++i) cnt *= t.shape[i];
+                        if (t.name.empty() || !have_off || t.offset + cnt > (long long)nfl) return bad("tensor outside the payload");
+                        wf.tensors.push_back(t);
+                        if (s.lit(',')) continue;
+                        if (!s.lit(']')) return bad("tensors end");
+                        break;
+                    }
+                }
+            } else if (!s.skip_value()) return bad("bad value");
+            if (s.lit(',')) continue;
+            if (!s.lit('}')) return bad("object end");
+            break;
+        }
+    }
+    if (!have_tensors || wf.tensors.empty()) return bad("no tensors");
+    return PMP_OK;
+}
+
+int net_id_of(const std::string &net)
+{
+    if (net == "Luma_Q") return PMP_NET_LUMA_Q;
+    if (net == "Luma_MSBD") return PMP_NET_LUMA_MSBD;
+    if (net == "Chroma_Q") return PMP_NET_CHROMA_Q;
+    if (net == "Chroma_MSBD") return PMP_NET_CHROMA_MSBD;
+    return -1;
+}
+
+}  // namespace pmp
+
+extern "C" int pmp_debug_read_weights_file(const char *path, int *net_id, int *qp, int *ntensors, int64_t *nfloats, double *checksum)
+{
+    pmp::WeightFile wf;
+    const int rc = pmp::read_pmpw(path, wf);
+    if (rc != PMP_OK) return rc;
+    if (net_id) *net_id = pmp::net_id_of(wf.net);
+    if (qp) *qp = wf.qp;
+    if (ntensors) *ntensors = (int)wf.tensors.size();
+    if (nfloats) *nfloats = (int64_t)wf.payload.size();
+    if (checksum) {   // sum over the tensors' elements (order of the manifest): what a caller of pmp_load_weights would see
+        double s = 0;
+        for (const auto &t : wf.tensors) {
+            long long cnt = 1;
+            for (int i = 0; i < t.ndim; ++i) cnt *= t.shape[i];
+            for (long long i = 0; i < cnt; ++i) s += wf.payload[(size_t)(t.offset + i)];
+        }
+        *checksum = s;
+    }
+    return PMP_OK;
+}

@@ -103,6 +103,29 @@ def main():
         assert lib.pmp_debug_pack_f16x3(wp, cout, cin, k, short.ctypes.data_as(C.POINTER(C.c_uint16)), n - 1, C.byref(kexp)) == n
         assert not short.any()
     assert lib.pmp_debug_pack_f16x3(None, 1, 1, 1, None, 0, None) == -1
+    # 6. the .pmpw weight container: the shipped QT-net files, and malformed files (truncated, bad magic, offsets beyond the payload)
+    from pmp_vvc_tip2023_amd import weights as W
+    wdir = W.default_weight_dir()
+    for fn in sorted(os.listdir(wdir)):
+        if not fn.endswith(".pmpw"):
+            continue
+        man, tens = W.load_pmpw(os.path.join(wdir, fn))
+        nid, qp, nt, nfl, cs = C.c_int(), C.c_int(), C.c_int(), C.c_int64(), C.c_double()
+        assert lib.pmp_debug_read_weights_file(os.path.join(wdir, fn).encode(), C.byref(nid), C.byref(qp), C.byref(nt), C.byref(nfl), C.byref(cs)) == 0
+        assert (nid.value, qp.value, nt.value) == (_lib.NET_IDS[man["net"]], man["qp"], len(tens))
+        ref = sum(float(np.sum(t.astype(np.float64))) for t in tens.values())
+        assert abs(cs.value - ref) <= 1e-6 * max(1.0, abs(ref)) and nfl.value == sum(t.size for t in tens.values())
+    good = open(os.path.join(wdir, "Luma_Q_22.pmpw"), "rb").read()
+    jl = int.from_bytes(good[6:10], "little")
+    cases = {"empty": b"", "magic": b"PMPW2\n" + good[6:], "cut_manifest": good[:10 + jl // 2], "cut_payload": good[:10 + jl + 100],
+             "huge_len": good[:6] + (2 ** 31).to_bytes(4, "little") + good[10:], "garbage_json": good[:10] + b"{" * jl + good[10 + jl:],
+             "no_tensors": good[:6] + (2).to_bytes(4, "little") + b"{}" + good[10 + jl:]}
+    for name, blob in cases.items():
+        pth = os.path.join(tmp, name + ".pmpw")
+        open(pth, "wb").write(blob)
+        rc = lib.pmp_debug_read_weights_file(pth.encode(), None, None, None, None, None)
+        assert rc in (-1, -4), (name, rc)
+    assert lib.pmp_debug_read_weights_file(os.path.join(tmp, "missing.pmpw").encode(), None, None, None, None, None) == -4
     print("hostasan checks passed")
 
 

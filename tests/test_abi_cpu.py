@@ -174,3 +174,26 @@ def test_product_library_has_no_ablation_knobs(lib):
     blob = open(_lib.LIB_PATH, "rb").read()
     assert b"PMP_CONV_VARIANT" not in blob
     assert b"abl" not in lib.pmp_version()
+
+
+def test_pmpw_container_reader_matches_python(lib, tmp_path):
+    """pmp_load_weights_file's parser (host code) against weights.load_pmpw on every shipped QT-net file and on a container
+    written here with odd shapes; a file for another net or QP is refused by name (checked without a GPU through the parser)."""
+    from pmp_vvc_tip2023_amd import weights as W
+    wdir = W.default_weight_dir()
+    files = [f for f in sorted(os.listdir(wdir)) if f.endswith(".pmpw")]
+    assert len(files) == 8
+    for fn in files:
+        man, tens = W.load_pmpw(os.path.join(wdir, fn))
+        nid, qp, nt, nfl, cs = C.c_int(), C.c_int(), C.c_int(), C.c_int64(), C.c_double()
+        assert lib.pmp_debug_read_weights_file(os.path.join(wdir, fn).encode(), C.byref(nid), C.byref(qp), C.byref(nt), C.byref(nfl), C.byref(cs)) == 0
+        assert (nid.value, qp.value, nt.value) == (_lib.NET_IDS[man["net"]], man["qp"], 20)
+        ref = sum(float(np.sum(t.astype(np.float64))) for t in tens.values())
+        assert abs(cs.value - ref) <= 1e-6 * max(1.0, abs(ref))
+    p = str(tmp_path / "x.pmpw")
+    W.save_pmpw(p, "Chroma_MSBD", 37, {"a.weight": np.arange(24, dtype=np.float32).reshape(2, 3, 2, 2), "b.bias": np.ones(5, np.float32),
+                                       "s": np.float32(3.0)}, source='quote " and \\ backslash')
+    nid, qp, nt, nfl, cs = C.c_int(), C.c_int(), C.c_int(), C.c_int64(), C.c_double()
+    assert lib.pmp_debug_read_weights_file(p.encode(), C.byref(nid), C.byref(qp), C.byref(nt), C.byref(nfl), C.byref(cs)) == 0
+    assert (nid.value, qp.value, nt.value, nfl.value) == (3, 37, 3, 30) and cs.value == 276 + 5 + 3
+    assert lib.pmp_debug_read_weights_file(str(tmp_path / "nope.pmpw").encode(), None, None, None, None, None) == -4
