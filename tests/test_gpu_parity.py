@@ -75,6 +75,50 @@ def test_logits_vs_oracle_fresh_inputs_and_chunking(eng, comp):
     assert np.array_equal(qt, qt2) and np.array_equal(bt, bt2) and np.array_equal(dire, dire2)
 
 
+_ORACLE_512 = {}
+
+
+def _oracle_512(comp, qp):
+    """Oracle logits and end-to-end flags of 512 fresh recipe-R blocks (computed once, shared by the three datapaths)."""
+    from oracle import nets_torch as O, postproc as P
+    from pmp_vvc_tip2023_amd import synth, weights as W
+    key = (comp, qp)
+    if key not in _ORACLE_512:
+        n = 512
+        y, u, v = synth.recipe_r_blocks(n, 1000 + qp + (7 if comp == "Chroma" else 0))
+        luma = comp == "Luma"
+        wq, _ = W.load_net_weights(comp + "_Q", qp)
+        wbd, _ = W.load_net_weights(comp + "_MSBD", qp, allow_synthetic=True)
+        x = O.luma_input(y) if luma else O.chroma_input(y, u, v)
+        oq, obt, odire = O.infer_qbd(wq, wbd, x, luma, batch=64)
+        flags = P.seq_post_process(oq, obt, odire, comp, 1, 64 * n, 64, None)
+        _ORACLE_512[key] = (y, u, v, oq, obt, odire, flags)
+    return _ORACLE_512[key]
+
+
+@pytest.mark.parametrize("comp", ["Luma", "Chroma"])
+@pytest.mark.parametrize("qp", [22, 27, 32, 37])
+def test_512_fresh_blocks_logits_and_end_to_end_flags_vs_oracle(eng, comp, qp):
+    """SURVEY 8(d) at a size that means something: 512 fresh blocks per component and QP.  Logits within 1e-3 of the torch oracle;
+    split flags of the HIP path (its own logits) against the oracle's end-to-end flags (its own logits).  'Bit-exact flags' is
+    only defined for identical logits: a value that sits within the logit difference of a rounding boundary
+    may legitimately land on the other side, so the audit counts those cells and allows mismatches only in blocks that have one."""
+    y, u, v, oq, obt, odire, (oh, ov, oq8, od8) = _oracle_512(comp, qp)
+    hor, ver, q8, d8, qt, bt, dire = eng.infer_postprocess(comp, qp, y, u, v, want_logits=True)
+    err = max(np.abs(qt - oq).max(), np.abs(bt - obt).max(), np.abs(dire - odire).max())
+    assert err < TOL, "%s QP%d logits off by %g" % (comp, qp, err)
+    margin = max(2e-4, 2 * float(err))
+    pooled = oq.reshape(-1, 4, 2, 4, 2).max(axis=(2, 4))                       # max_pool2d(qt, 2), Metrics.py:632
+    near_qt = (np.abs(pooled - np.floor(pooled) - 0.5) < margin).any(axis=(1, 2))
+    near_bt = (np.abs(obt - np.floor(obt) - 0.5) < margin).any(axis=(1, 2, 3))    # np.round boundaries, Map2Partition.py:104
+    near_dr = (np.abs(np.abs(odire) - 0.5) < margin).any(axis=(1, 2, 3))          # th_round thresholds, :30-35
+    risky = near_qt | near_bt | near_dr
+    bad = ((hor != oh).any(axis=(1, 2)) | (ver != ov).any(axis=(1, 2)) | (q8 != oq8.astype(np.uint8)).any(axis=(1, 2)) |
+           (d8 != od8).any(axis=(1, 2, 3)))
+    assert not (bad & ~risky).any(), "%d blocks differ from the oracle's flags without a value near a rounding boundary" % int((bad & ~risky).sum())
+    assert bad.sum() <= 8, "%d of 512 blocks differ (near-boundary blocks: %d)" % (int(bad.sum()), int(risky.sum()))
+
+
 @pytest.mark.parametrize("shape", [(8, 32, 32, 48, 64, 3), (8, 32, 32, 16, 64, 3), (4, 16, 16, 80, 64, 5), (8, 16, 16, 96, 32, 3),
                                    (4, 16, 16, 48, 16, 3), (8, 32, 32, 32, 64, 1), (4, 48, 32, 64, 64, 3)])
 def test_conv_kernel_shapes_beyond_the_nets(eng, shape):
@@ -96,6 +140,24 @@ def test_conv_kernel_shapes_beyond_the_nets(eng, shape):
             finally:
                 eng.lib.pmp_debug_set_conv_variant(2)
             assert d.value < 1e-4 * max(1.0, r.value), (shape, variant, d.value, r.value)
+
+
+def test_small_calls_need_small_workspaces():
+    """The activation arena is sized for the blocks a pass runs, not for the chunk (include/pmp.h): a 4-block call stays in the
+    tens of megabytes, so several contexts (or a co-tenant) fit beside each other on one GPU."""
+    from pmp_vvc_tip2023_amd import engine, synth
+    e2 = engine.Engine(0, allow_synthetic_mtt=True)
+    try:
+        assert e2.workspace_bytes() == 0
+        y, u, v = synth.recipe_r_blocks(4, 3)
+        e2.infer_postprocess("Luma", 22, y)
+        assert 0 < e2.workspace_bytes() <= 4 * 2.75 * 2 ** 20
+        e2.infer_postprocess("Chroma", 22, y, u, v)
+        e2.set_precision("bf16x6")
+        e2.infer_postprocess("Luma", 22, y)
+        assert e2.workspace_bytes() <= 4 * 4.1 * 2 ** 20
+    finally:
+        e2.close()
 
 
 def test_default_chunk_boundary(eng):
