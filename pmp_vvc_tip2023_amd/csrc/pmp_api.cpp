@@ -575,6 +575,7 @@ int pmp_debug_conv_bench(pmp_ctx *c, int n, int h, int w, int cin, int cout, int
         b.x = dxs; b.x_stride = nx; b.w = dwx; b.out = dys; b.out_stride = ny;
         b.N = n; b.H = h; b.W = w; b.Cin = cin; b.Cout = cout; b.KH = b.KW = k; b.relu = 1;
         b.out_scale = std::ldexp(1.f, -kexp);
+        b.zeros = c->d_sat + 16;
         auto launch_split = [&]() { return h2 ? launch_conv_h2(c->stream, b) : launch_conv_x6(c->stream, b); };
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);

@@ -44,6 +44,7 @@ struct ConvX6Args {
     unsigned long long *dbg;   // diagnostic builds only: 8 stamps per workgroup (nullptr otherwise)
     float out_scale;           // f16x3 only: 1/S of the power-of-two weight scaling (conv_f16x3.hip)
     unsigned *sat;             // f16x3 only: sticky flag raised when a stored activation exceeded the fp16 range (may be nullptr)
+    const void *zeros;         // f16x3 only: >= 16 zero bytes in device memory (source of out-of-image halo pieces, conv_f16x3_t32.hip)
 };
 hipError_t launch_conv_x6(hipStream_t s, const ConvX6Args &a);
 hipError_t launch_f32_to_split3(hipStream_t s, const float *x, unsigned short *out, size_t n, size_t plane_stride);
@@ -51,6 +52,9 @@ hipError_t launch_split3_to_f32(hipStream_t s, const unsigned short *x, float *o
 // Same operation on "split-2" activations (two fp16 planes) with three fp16 MFMA products per term (conv_f16x3.hip).
 // Weights packed [K-step][2 splits][Cout/16][64 lanes][8 fp16], pre-multiplied by 1/out_scale.
 hipError_t launch_conv_h2(hipStream_t s, const ConvX6Args &a);
+// conv_f16x3_t32.hip: the 3x3 64->64 trunk convolution on 32x16 tiles (LDS-DMA halo, hand-counted vmcnt)
+bool conv_h2_t32_applicable(const ConvX6Args &a);
+hipError_t launch_conv_h2_t32(hipStream_t s, const ConvX6Args &a);
 hipError_t launch_f32_to_split2(hipStream_t s, const float *x, unsigned short *out, size_t n, size_t plane_stride, unsigned *sat = nullptr);
 hipError_t launch_split2_to_f32(hipStream_t s, const unsigned short *x, float *out, size_t n, size_t plane_stride);
 
