@@ -6,7 +6,7 @@ TAG=${1:-r01}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --steps 3 --warmup 1 --cpu-sample 0"
+BENCH="python3 $PWD/bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-extras"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
 # PMC passes (counters only; never combined with tracing).  SQ block has 8 slots, TCC 4 (FETCH_SIZE 3, WRITE_SIZE 2).
