@@ -106,9 +106,11 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
                                               unsigned long long *dbg, H2Carry<KH, KW, NT, W8> &c, bool first, int n2, int ty2, int tx2)
 {
     constexpr int NTHR = W8 == 1 ? 512 : 256;
+    constexpr bool STAGE = W8 != 3;   // W8 == 3: a fifth wave of the workgroup fills the halo buffers by LDS-DMA (conv_h2_ld_kernel); the compute
+                                      // waves issue no halo request at all - only the barriers of the staging protocol remain
     unsigned long long t_pro = 0, t_k = 0, t_s = 0, t_b = 0, tmark = 0;   // diagnostic accumulators (ABL & 128)
     if (ABL & 128) tmark = h2_stamp();
-    typedef GeoH<KH, KW, 16, NTHR> G;
+    typedef GeoH<KH, KW, 16, NTHR, W8 == 3> G;
     typedef WaveTile<NT, W8> WT;
     constexpr int RW = WT::RW, CW = WT::CW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, xl = lane & 15, g = lane >> 4;
@@ -140,7 +142,7 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
     // it; one K-step of lead (0.8-1.5 k cycles) is less than that round trip, two are more.
     f16x8 (&w1n)[CW] = c.w1n, (&w0nn)[CW] = c.w0nn;
     if (!CHAIN || first) {   // a chained tile finds its weights in the carry and its first halo group in LDS buffer 0
-        h2_plan<KH, KW, NTHR>(plan, plane_stride, H, W, ty, tx);
+        if (STAGE) h2_plan<KH, KW, NTHR>(plan, plane_stride, H, W, ty, tx);
 #pragma unroll
         for (int nt = 0; nt < CW; ++nt) {
             if (W0DB) w0n[nt] = wl[(0 * NT + nt) * 64]; else w0[nt] = wl[(0 * NT + nt) * 64];
@@ -150,11 +152,13 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
                 w0nn[nt] = w2[(0 * NT + nt) * 64]; w1n[nt] = w2[(1 * NT + nt) * 64];
             }
         }
-        __syncthreads();
-        h2_stage_load<KH, KW, NTHR>(plan, grp0, r);
-        if (DEEP && paired) h2_stage_load<KH, KW, NTHR>(plan, grp0 + grp_sz, reinterpret_cast<u32x4 (&)[G::NLD]>(rb));   // group 1 exists: CB is even
-        h2_stage_store<KH, KW, NTHR>(plan, lds, r);
-        __syncthreads();
+        if (STAGE) {
+            __syncthreads();
+            h2_stage_load<KH, KW, NTHR>(plan, grp0, r);
+            if (DEEP && paired) h2_stage_load<KH, KW, NTHR>(plan, grp0 + grp_sz, reinterpret_cast<u32x4 (&)[G::NLD]>(rb));   // group 1 exists: CB is even
+            h2_stage_store<KH, KW, NTHR>(plan, lds, r);
+        }
+        __syncthreads();   // loader-wave form: the loader has DMA'd group 0 and waited for it before this barrier
     } else if (LEAN) {
         // 168 VGPRs cannot carry the plan and four weight sets across the epilogue: a chained tile of the three-workgroup
         // form recomputes its plan and requests its first weights again (L2 hits); only the halo group in LDS is carried
@@ -189,7 +193,8 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
         if (CHAINF) h2_plan<KH, KW, NTHR>(plan, plane_stride, H, W, ty2, tx2);
         const unsigned short *nxt_grp = CHAINF ? x + (size_t)n2 * CB * grp_sz
                                                : grp0 + (size_t)min(cb + DIST, CB - 1) * grp_sz;   // clamped (odd group in a deep pair before the tail)
-        const char *buf = reinterpret_cast<const char *>(lds + (cb & 1) * G::BUF);
+        const int bcur = cb & 1, bprev = (cb + 1) & 1;
+        const char *buf = reinterpret_cast<const char *>(lds + bcur * G::BUF);
         auto xaddr = [&](int ks) -> const char * {   // in-group tap pair of K-step ks
             const int j = MODE == 2 ? ks - 1 : ks;
             int tA = 2 * j, tB = 2 * j + 1;
@@ -203,8 +208,8 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
             // cross-group tap read from the partner buffer instead of carried in 64 registers - with a barrier before that
             // buffer's first rolling store.
             constexpr int RS = W8 == 1 ? 4 : 2, SUB = RW / RS;   // 2-row sub-steps: 4-row ones spill (-15 %), 1-row ones expose more LDS round trips (-1 %)
-            const char *part = reinterpret_cast<const char *>(lds + ((cb + 1) & 1) * G::BUF);
-            if (NK == 0 && FETCH) h2_stage_load<KH, KW, NTHR>(plan, nxt_grp, rl);   // 1x1 source, even group: only fetch the partner group
+            const char *part = reinterpret_cast<const char *>(lds + bprev * G::BUF);
+            if (STAGE && NK == 0 && FETCH) h2_stage_load<KH, KW, NTHR>(plan, nxt_grp, rl);   // 1x1 source, even group: only fetch the partner group
 #pragma unroll
             for (int ks = 0; ks < NK; ++ks) {
                 asm volatile("" : "+v"(tapsel));
@@ -235,8 +240,8 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
                         for (int nt = 0; nt < CW; ++nt) w0[nt] = w0n[nt];
 #pragma unroll
                         for (int nt = 0; nt < CW; ++nt) { w1n[nt] = wf[(1 * NT + nt) * 64]; w0n[nt] = wf[(0 * NT + nt) * 64]; }
-                        if (FETCH) h2_stage_load<KH, KW, NTHR>(plan, nxt_grp, rl, ks * PER, (ks + 1) * PER);   // slices: one burst per group measured 1 % slower here
-                        if (more && ks >= LAG)
+                        if (STAGE && FETCH) h2_stage_load<KH, KW, NTHR>(plan, nxt_grp, rl, ks * PER, (ks + 1) * PER);   // slices: one burst per group measured 1 % slower here
+                        if (STAGE && more && ks >= LAG)
                             h2_stage_store<KH, KW, NTHR>(plan, lds + ((cb + 1) & 1) * G::BUF, rs, (ks - LAG) * PER, (ks - LAG + 1) * PER);
                     } else if (h == SUB - 1) {
 #pragma unroll
@@ -362,7 +367,7 @@ __device__ __forceinline__ void h2_accumulate(const unsigned short *__restrict__
         }
         if (ABL & 128) { const unsigned long long t = h2_stamp(); t_k += t - tmark; tmark = t; }
         // the store goes to the buffer nobody reads during this group (the deferred tap travels in registers)
-        if (more && !(ABL & 1))
+        if (STAGE && more && !(ABL & 1))
             h2_stage_store<KH, KW, NTHR>(plan, lds + ((cb + 1) & 1) * G::BUF, rs, ROLL && NK > LAG ? (NK - LAG) * PER : 0);
         if (ABL & 128) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t = h2_stamp(); t_s += t - tmark; tmark = t; }
         __syncthreads();
@@ -523,6 +528,94 @@ __global__ __launch_bounds__(256, LEAN ? 3 : 2) void conv_h2_persist_kernel(Conv
     }
 }
 
+// ---- loader-wave form (Cout = 64, no shortcut source, even number of channel groups; opt-in, pmp_debug_set_conv_variant(6)).
+// A wave's loads return IN ORDER: in the kernels above every halo request a compute wave issues stands in front of that wave's own
+// weight stream (L1 hits) for a whole HBM round trip - the timing-only builds of conv_f16x3_t32.hip put 27 % of a launch on exactly
+// that.  Here a FIFTH wave of the workgroup (threads 256..319) does nothing but fill the halo buffers by LDS-DMA, a whole channel
+// group ahead; the four compute waves run the LEAN K-loop with no halo request in their queues.  MEASURED SLOWER than the default:
+// 327 against 385 TFLOP/s on the 3x3 64->64 class (5x5: 480 against 520).  A workgroup's life does get shorter (56 k against 68 k cycles
+// at 64x64), but registers are allocated per kernel, so the loader costs a full 146-VGPR wave: 12 wave slots per CU hold two
+// five-wave workgroups = 8 compute waves instead of 12; at 128 VGPRs (three workgroups, 116 B of scratch) it runs 310.  Together
+// with the counters (matrix pipes busy 69 % of the cycles at an in-kernel clock of 1.67 GHz: 0.69 x 1.67 / 2.4 = the 0.48 of the
+// roofline) the reading is that this class is no longer latency-bound: stalls removed come back as a lower clock.
+// The loader takes part in every barrier of the staging protocol:
+//   B0: group 0 is in buffer 0        E(g): group g is consumed, group g+1 has landed        X(g), odd g: the cross step has read
+//   the even group's last tap, its buffer may be refilled
+// Same K order, same products per accumulator: bit-identical results.
+__device__ __forceinline__ void h2_dma16(const void *src, unsigned lds_byte_base)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_byte_base) : "memory");
+}
+
+template <int KH, int KW>
+__device__ __forceinline__ void h2_loader(const ConvX6Args &a, int n, int ty, int tx, u32x4 *lds)
+{
+    typedef GeoH<KH, KW, 16, 256, true> G;
+    constexpr int PY = KH / 2, PX = KW / 2;
+    const int lane = threadIdx.x & 63, H = a.H, W = a.W, CB = a.Cin >> 4;
+    const size_t grp_sz = (size_t)H * W * 16;
+    const unsigned short *grp0 = a.x + (size_t)n * CB * grp_sz;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds;
+    // the per-lane source offsets are the same for every channel group: worked out once (21 / 25 registers - the loader has nothing
+    // else to keep), so that a group's DMAs go out back to back
+    unsigned off[G::NQ];
+    unsigned in_image = 0;
+#pragma unroll
+    for (int q = 0; q < G::NQ; ++q) {
+        const int i = q * 64 + lane, ic = min(i, G::PIECES - 1);
+        const int sp = ic >= G::PLANE ? 1 : 0, j = ic - sp * G::PLANE, pix = j >> 1, half = j & 1;
+        const int row = pix / G::TW, col = pix - row * G::TW;
+        const int gy = ty * 16 + row - PY, gx = tx * 16 + col - PX;
+        if (i < G::PIECES && gy >= 0 && gy < H && gx >= 0 && gx < W) in_image |= 1u << q;   // else zero padding (or a dummy piece past the tile)
+        off[q] = (unsigned)((size_t)sp * a.x_stride + ((size_t)max(gy, 0) * W + max(gx, 0)) * 16 + half * 8);
+    }
+    auto fill = [&](int cb, int buf) __attribute__((always_inline)) {
+        const unsigned short *grp = grp0 + (size_t)cb * grp_sz;
+        const unsigned lb = lds_base + (unsigned)(buf * G::BUF * 16);
+#pragma unroll
+        for (int q = 0; q < G::NQ; ++q) {
+            const void *src = ((in_image >> q) & 1u) ? (const void *)(grp + off[q]) : a.zeros;
+            h2_dma16(src, __builtin_amdgcn_readfirstlane(lb + (unsigned)(q * 1024)));
+        }
+    };
+    // (A third buffer with the loader two groups ahead measured no better: 313 against 327 TFLOP/s - the waits are not what binds.)
+    fill(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                       // B0
+    for (int cb = 0; cb < CB; ++cb) {
+        if (cb & 1) asm volatile("s_barrier" ::: "memory");                             // X(cb): buffer (cb + 1) & 1 is free now
+        if (cb + 1 < CB) fill(cb + 1, (cb + 1) & 1);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                   // E(cb)
+    }
+}
+
+template <int KH, int KW>
+__global__ __launch_bounds__(320, 3) void conv_h2_ld_kernel(ConvX6Args a)
+{
+    typedef GeoH<KH, KW, 16, 256, true> G;
+    __shared__ u32x4 lds[2 * G::BUF];
+    const int tiles_x = a.W >> 4, tiles = tiles_x * (a.H >> 4);
+    int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    const int n = bid / tiles, t = bid - n * tiles, ty = t / tiles_x, tx = t - ty * tiles_x;
+    if (threadIdx.x >= 256) {   // wave 4: the loader
+        h2_loader<KH, KW>(a, n, ty, tx, lds);
+        return;
+    }
+    typedef WaveTile<4, 3> WT;
+    f32x4 acc[WT::RW][WT::CW];
+#pragma unroll
+    for (int m = 0; m < WT::RW; ++m)
+#pragma unroll
+        for (int nt = 0; nt < WT::CW; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+        H2Carry<KH, KW, 4, 3> carry;
+        h2_accumulate<KH, KW, 4, 0, false, true, 3>(a.x, a.x_stride, a.w, a.Cin, a.H, a.W, n, ty, tx, lds, acc, nullptr, carry, true, n, ty, tx);
+    }
+    h2_epilogue<4, 0, 3>(a, acc, n, ty, tx);
+}
+
 template <int NT, int ABL, int W8>
 __device__ __forceinline__ void h2_epilogue(const ConvX6Args &a, f32x4 (&acc)[WaveTile<NT, W8>::RW][WaveTile<NT, W8>::CW], int n, int ty, int tx)
 {
@@ -637,6 +730,12 @@ template <int KH, int KW>
 static hipError_t launch_h2(hipStream_t s, const ConvX6Args &a)
 {
     const int grid = a.N * (a.H >> 4) * (a.W >> 4);
+    if constexpr (KH > 1) {   // loader-wave form (5 waves per workgroup): opt-in for A/B
+        if (a.Cout == 64 && !a.x_sc && !((a.Cin >> 4) & 1) && a.zeros && g_conv_variant == 6) {
+            hipLaunchKernelGGL((conv_h2_ld_kernel<KH, KW>), dim3(grid), dim3(320), 0, s, a);
+            return hipGetLastError();
+        }
+    }
     // the 1x1 shortcut source is a separate instantiation: its extra live state would spill in the common kernel
 #define PMP_H2_LAUNCH(NT)                                                                                          \
     if (a.x_sc) hipLaunchKernelGGL((conv_h2_kernel<KH, KW, NT, true>), dim3(grid), dim3(256), 0, s, a);           \

@@ -137,15 +137,17 @@ __device__ __forceinline__ void store_split2_4_nt(unsigned short *p, size_t plan
 }
 
 // ---- geometry shared by conv_f16x3.hip and conv_f16x3_ws.hip
-template <int KH, int KW, int TR = 16, int NTHR = 256>   // TR = output rows per workgroup tile (16 columns always), NTHR = threads that stage it
+template <int KH, int KW, int TR = 16, int NTHR = 256, bool DMA = false>   // TR = output rows per workgroup tile (16 columns always), NTHR = threads that stage it
 struct GeoH {
     static constexpr int TH = TR + KH - 1, TW = 16 + KW - 1, TAPS = KH * KW, NKS = (TAPS + 1) / 2;
     static constexpr int PLANE = TH * TW * 2;            // 16-B pieces per split plane (32 B per pixel)
     static constexpr int PIECES = 2 * PLANE;             // per buffer
     static constexpr int NLD = (PIECES + NTHR - 1) / NTHR;
-    static constexpr int BUF = PIECES + 1;               // pieces reserved per LDS buffer: one spare slot, so that every staging thread
-                                                         // stores all NLD of its pieces unconditionally (a conditional store lets hipcc
-                                                         // sink the global load into the branch, next to its use, and wait for it there)
+    static constexpr int NQ = (PIECES + 63) / 64;        // DMA form: wave-instructions of 64 pieces per buffer
+    static constexpr int BUF = DMA ? NQ * 64 : PIECES + 1;   // pieces reserved per LDS buffer.  Register staging: one spare slot, so
+                                                         // that every staging thread stores all NLD of its pieces unconditionally (a
+                                                         // conditional store lets hipcc sink the global load into the branch, next to
+                                                         // its use, and wait for it there).  DMA form (loader wave): whole wave-instructions
 };
 
 // Wave tile: RW rows x CW cout groups of the workgroup's 16 rows x NT groups (4 waves).  At Cout >= 32 a wave takes 8 rows
