@@ -3,7 +3,8 @@
 # VTM encoder with tools/vtm_build/pmp_hook.cpp predicting the partition maps IN-PROCESS through libpmp_hip.so must produce the
 # bitstream the stock patched encoder produces from the text files of the Python driver.  Needs the binaries that
 # tools/vtm_build builds in the build container, staged under tools/vtm_build/_bin/ (git-ignored: build products of the
-# reference's sources never enter the history), and the encoder cfg next to them.  Output: gpurun_out/n4/summary.txt
+# reference's sources never enter the history), and the encoder cfg next to them; take tools/vtm_build/_bin/ out of .gpurunignore for
+# that one call (it is listed there so that the 13 MB of binaries do not travel with every other gpurun).  Output: gpurun_out/n4/summary.txt
 set -u
 ROOT=$PWD
 BIN=$ROOT/tools/vtm_build/_bin
