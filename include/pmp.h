@@ -189,12 +189,18 @@ const char *pmp_ktime_name(int cls);
 /* Synchronises, then returns launches / total milliseconds / algorithmic FLOPs accumulated for the class. */
 int pmp_ktime_get(pmp_ctx *ctx, int cls, int64_t *launches, double *ms, double *flops);
 
-/* ---- measurement hook: selects the conv kernel build used by later launches (process-wide).
- *      fp32 datapath: 0 = un-pipelined kernel, 1 = software-pipelined (3 waves/SIMD), 2 = fully pipelined, 2 waves/SIMD
- *      (default).  f16x3 datapath, Cout = 64 kernels without shortcut source (conv_f16x3.hip): 3 = two workgroups per
- *      CU (236-256 VGPRs, 8-row pixel fragments), 4 = that form made persistent, 5 = the default form made persistent (3x3 only), 7 = 512-thread workgroups, 8 = 16-row x 1-cout-group wave tiles (3x3 only), anything else = three workgroups per CU
- *      (168 VGPRs, default).  10 + bits = timing-only ablation builds (wrong results; tools/conv_x6_bench.py).
- *      Variants 0..8 compute bit-identical results per datapath; tools/conv_ab.py uses this for in-process A/B timing. ---- */
+/* ---- measurement hook: selects the conv kernel build used by later launches (process-wide), for in-process A/B timing
+ *      (tools/conv_ab.py).  Every variant this library accepts (0..9) computes bit-identical results per datapath
+ *      (tests/test_gpu_parity.py::test_f16x3_conv_variants_agree); the timing-only builds that do not (10 and above) exist only in
+ *      the measurement library libpmp_hip_abl.so (make abl) and are rejected here.
+ *      fp32 datapath: 0 = un-pipelined kernel, 1 = software-pipelined (3 waves/SIMD), 2 = fully pipelined, 2 waves/SIMD (default).
+ *      f16x3 datapath, Cout = 64 kernels (conv_f16x3.hip; anything else = the default: three workgroups per CU, 168 VGPRs):
+ *        1 = the 32-channel-shortcut instantiations at three workgroups per CU (measures the same as their default two)
+ *        3 = two workgroups per CU (236-256 VGPRs, 8-row pixel fragments)     4 = that form made persistent
+ *        5 = the default form made persistent (3x3 only)                       6 = loader-wave form (fifth wave fills the halo by LDS-DMA)
+ *        7 = 512-thread workgroups                                             8 = 16-row x 1-cout-group wave tiles (3x3 only)
+ *        9 = 32x16 tiles, 64-cout wave tiles, LDS-DMA, hand-counted vmcnt (conv_f16x3_t32.hip; 3x3 64->64 only)
+ *      All of them measured slower than (or equal to) the default: DESIGN.md 4.1a. ---- */
 int pmp_debug_set_conv_variant(int variant);
 
 /* ---- test hook (host only, no GPU needed): the f16x3 weight packing of one OIHW conv tensor (conv_f16x3.hip).

@@ -744,7 +744,9 @@ static hipError_t launch_h2(hipStream_t s, const ConvX6Args &a)
     case 1: PMP_H2_LAUNCH(1); break;
     case 2: PMP_H2_LAUNCH(2); break;
     case 4:
-        if (KH > 1 && a.x_sc && a.Csc == 32 && g_conv_variant != 3) {   // variant 3: the general shortcut pass, for A/B timing
+        if (KH > 1 && a.x_sc && a.Csc == 32 && g_conv_variant == 1) {   // A/B: the 32-channel shortcut form at three workgroups per CU
+            hipLaunchKernelGGL((conv_h2_kernel<KH, KW, 4, 2, 0, true>), dim3(grid), dim3(256), 0, s, a);
+        } else if (KH > 1 && a.x_sc && a.Csc == 32 && g_conv_variant != 3) {   // variant 3: the general shortcut pass, for A/B timing
             // two workgroups per CU: in the 168-VGPR form these kernels measure the same (5x5 class 5.94 vs 5.95 ms per 1024 blocks)
             hipLaunchKernelGGL((conv_h2_kernel<KH, KW, 4, 2>), dim3(grid), dim3(256), 0, s, a);
 #ifdef PMP_ABLATION   // timing-only builds (wrong results): only in libpmp_hip_abl.so, never in the product library
