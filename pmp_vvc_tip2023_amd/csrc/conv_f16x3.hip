@@ -22,6 +22,7 @@
 //   phase A: x0*w1 -> request the next w1 into the same registers     phase B1: x0*w0 -> read the next K-step's x0
 //   phase B2: x1*w0 -> move the prefetched w0 over
 // Measurements, ablations and the variants that did not pay: DESIGN.md 4.1a.
+#include <cstdio>
 #include <type_traits>
 
 #include "pmp_kernels.h"
@@ -533,9 +534,9 @@ __global__ __launch_bounds__(256, LEAN ? 3 : 2) void conv_h2_persist_kernel(Conv
 // weight stream (L1 hits) for a whole HBM round trip - the timing-only builds of conv_f16x3_t32.hip put 27 % of a launch on exactly
 // that.  Here a FIFTH wave of the workgroup (threads 256..319) does nothing but fill the halo buffers by LDS-DMA, a whole channel
 // group ahead; the four compute waves run the LEAN K-loop with no halo request in their queues.  MEASURED SLOWER than the default:
-// 327 against 385 TFLOP/s on the 3x3 64->64 class (5x5: 480 against 520).  A workgroup's life does get shorter (56 k against 68 k cycles
-// at 64x64), but registers are allocated per kernel, so the loader costs a full 146-VGPR wave: 12 wave slots per CU hold two
-// five-wave workgroups = 8 compute waves instead of 12; at 128 VGPRs (three workgroups, 116 B of scratch) it runs 310.  Together
+// 327 against 385 TFLOP/s on the 3x3 64->64 class (5x5: 480 against 520) at 146 VGPRs, where 12 wave slots per CU hold two five-wave
+// workgroups = 8 compute waves instead of 12; 310-320 at 128 VGPRs with three workgroups resident (occupancy API), where one round
+// of workgroups takes 43.2 us against the default's 38.7: at equal residency a workgroup lives LONGER with the loader.  Together
 // with the counters (matrix pipes busy 69 % of the cycles at an in-kernel clock of 1.67 GHz: 0.69 x 1.67 / 2.4 = the 0.48 of the
 // roofline) the reading is that this class is no longer latency-bound: stalls removed come back as a lower clock.
 // The loader takes part in every barrier of the staging protocol:
@@ -649,26 +650,36 @@ __device__ __forceinline__ void h2_epilogue(const ConvX6Args &a, f32x4 (&acc)[Wa
     // (row m + (g&1), xl) - one v_permlane16_swap per register (gfx950) exchanges that form with the accumulator layout (4
     // couts 4g.. of rows m and m+1).  Half the vector-memory instructions of 8-byte accesses: the epilogue is issue-bound.
     const unsigned off0w = off0 - (unsigned)(g * 4) + (unsigned)(8 * (g >> 1)) + (unsigned)(g & 1) * row_el;
+    // CHUNK (loader-wave form, 128 VGPRs): one cout group's residual fragments at a time - the next group's are requested after this
+    // group's values are final and BEFORE its stores - instead of all of them up front (64 registers next to 64 accumulators).
+    constexpr bool CHUNK = W8 == 3;
+    u32x4 ra[RW / 2][CHUNK ? 1 : CW], rbv[RW / 2][CHUNK ? 1 : CW];
+    auto res_load = [&](int nt, int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < RW; m += 2) {
+            const unsigned off = off0w + (unsigned)m * row_el + (unsigned)nt * (unsigned)grp;
+            ra[m >> 1][slot] = *reinterpret_cast<const u32x4 *>(a.res + off);
+            rbv[m >> 1][slot] = *reinterpret_cast<const u32x4 *>(a.res + off + a.res_stride);
+        }
+    };
+    auto res_add = [&](int nt, int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < RW; m += 2) {
+            u32x4 p = ra[m >> 1][slot], q = rbv[m >> 1][slot];
+            rows16_swap(p);
+            rows16_swap(q);
+            acc[m][nt] = acc[m][nt] * inv_scale + (h2_lo4(p) + h2_lo4(q));        // undo the power-of-two weight scaling (exact)
+            acc[m + 1][nt] = acc[m + 1][nt] * inv_scale + (h2_hi4(p) + h2_hi4(q));
+        }
+    };
     if (a.res) {
-        u32x4 ra[RW / 2][CW], rbv[RW / 2][CW];
+        if (CHUNK) { res_load(0, 0); res_add(0, 0); }
+        else {
 #pragma unroll
-        for (int nt = 0; nt < CW; ++nt)
+            for (int nt = 0; nt < CW; ++nt) res_load(nt, CHUNK ? 0 : nt);
 #pragma unroll
-            for (int m = 0; m < RW; m += 2) {
-                const unsigned off = off0w + (unsigned)m * row_el + (unsigned)nt * (unsigned)grp;
-                ra[m >> 1][nt] = *reinterpret_cast<const u32x4 *>(a.res + off);
-                rbv[m >> 1][nt] = *reinterpret_cast<const u32x4 *>(a.res + off + a.res_stride);
-            }
-#pragma unroll
-        for (int nt = 0; nt < CW; ++nt)
-#pragma unroll
-            for (int m = 0; m < RW; m += 2) {
-                u32x4 p = ra[m >> 1][nt], q = rbv[m >> 1][nt];
-                rows16_swap(p);
-                rows16_swap(q);
-                acc[m][nt] = acc[m][nt] * inv_scale + (h2_lo4(p) + h2_lo4(q));        // undo the power-of-two weight scaling (exact)
-                acc[m + 1][nt] = acc[m + 1][nt] * inv_scale + (h2_hi4(p) + h2_hi4(q));
-            }
+            for (int nt = 0; nt < CW; ++nt) res_add(nt, CHUNK ? 0 : nt);
+        }
     } else {
 #pragma unroll
         for (int nt = 0; nt < CW; ++nt)
@@ -687,6 +698,7 @@ __device__ __forceinline__ void h2_epilogue(const ConvX6Args &a, f32x4 (&acc)[Wa
             amax = sat_amax4(amax, v);
             acc[m][nt] = v;
         }
+        if (CHUNK && a.res && nt + 1 < CW) res_load(nt + 1, 0);   // before this group's stores (the output may alias the residual tensor)
         if (!a.pool) {
             if (a.out_f32) {
 #pragma unroll
@@ -722,6 +734,7 @@ __device__ __forceinline__ void h2_epilogue(const ConvX6Args &a, f32x4 (&acc)[Wa
                 }
             }
         }
+        if (CHUNK && a.res && nt + 1 < CW) res_add(nt + 1, 0);
     }
     if (!a.out_f32) sat_report(a.sat, amax);   // fp32 outputs are not clamped
 }
@@ -732,6 +745,10 @@ static hipError_t launch_h2(hipStream_t s, const ConvX6Args &a)
     const int grid = a.N * (a.H >> 4) * (a.W >> 4);
     if constexpr (KH > 1) {   // loader-wave form (5 waves per workgroup): opt-in for A/B
         if (a.Cout == 64 && !a.x_sc && !((a.Cin >> 4) & 1) && a.zeros && g_conv_variant == 6) {
+#ifdef PMP_ABLATION
+            { static bool once = false; if (!once) { once = true; int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_h2_ld_kernel<KH, KW>, 320, 0);
+              fprintf(stderr, "conv_h2_ld_kernel<%d,%d>: occupancy API says %d workgroups of 320 threads per CU\n", KH, KW, nb); } }
+#endif
             hipLaunchKernelGGL((conv_h2_ld_kernel<KH, KW>), dim3(grid), dim3(320), 0, s, a);
             return hipGetLastError();
         }
