@@ -209,8 +209,12 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    if local_rank >= torch.cuda.device_count():          # smoke tests: several ranks on one GPU (gloo)
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    if local_rank >= torch.cuda.device_count():
+        if world > 1 and os.environ.get("PMP_DIST_BACKEND", "nccl") == "nccl":
+            raise SystemExit("bench.py: rank %d of %d has no GPU of its own (%d visible): RCCL needs one GPU per rank "
+                             "(PMP_DIST_BACKEND=gloo lets several ranks share a GPU, for smoke tests only)"
+                             % (rank, world, torch.cuda.device_count()))
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)   # smoke tests: several ranks on one GPU (gloo)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
