@@ -490,6 +490,49 @@ def test_config4_4k_frame_sharded_equals_unsharded(eng, oracle_lib):
         assert h.reshape(33, 60, 16, 16)[:, :, 0, :].all() and vv.reshape(33, 60, 16, 16)[:, :, :, 0].all()
 
 
+def test_config4_eight_4k_frames_all_qps_through_the_driver(tmp_path):
+    """BASELINE.json configs[3]'s input on the one GPU of the test box: 8 synthetic 3840x2160 frames, Luma + Chroma x 4 QPs through the
+    CLI driver (device-resident blocks, packed records, writer threads).  Every file has the geometry the VTM parser expects
+    (EncAppCfg.cpp:4243-4250: 528 x 960 cells, 8 frames) and the partition invariants; and because frames are independent, frame 5
+    of the 8-frame files equals the file a one-frame sequence made of that frame gives - the property the frame-sharded
+    multi-GPU run rests on (tests/test_parallel_cpu.py covers the gather itself)."""
+    import os
+    from pmp_vvc_tip2023_amd import inference_qbd as D, synth
+    W_, H_, F_ = 3840, 2160, 8
+    y, u, v = synth.recipe_r_frames(F_, H_, W_, 4)
+    inp = tmp_path / "in"; cfg = tmp_path / "cfg"
+    inp.mkdir(); cfg.mkdir()
+    for name, frames in (("All", range(F_)), ("One", [5])):
+        fn = "%s_3840x2160_30.yuv" % name
+        with open(inp / fn, "wb") as f:
+            for i in frames:
+                f.write(y[i].tobytes()); f.write(u[i].tobytes()); f.write(v[i].tobytes())
+        (cfg / (name + ".cfg")).write_text("InputFile : %s\nInputBitDepth : 8\n" % fn)
+    (inp / "table.txt").write_text("All,All_3840x2160_30.yuv,3840,2160,8,30\nOne,One_3840x2160_30.yuv,3840,2160,1,30\n#end!!!!\n")
+    D.main(["--jobID", "c4", "--inputDir", str(inp), "--outDir", str(tmp_path / "out"), "--seqTable", "table.txt", "--cfgDir", str(cfg),
+            "--ssRatio", "1", "--seqNum", "2", "--allowSyntheticMTT"])
+    pm = tmp_path / "out" / "c4" / "PartitionMat"
+    per_frame = 5 * 528 * 960 + 264 * 480                   # lines per frame (SURVEY A.5)
+    for comp in ("Luma", "Chroma"):
+        for qp in (22, 27, 32, 37):
+            allf = open(pm / ("All_3840x2160_30_%s_QP%d_PartitionMat.txt" % (comp, qp)), "rb").read()
+            one = open(pm / ("One_3840x2160_30_%s_QP%d_PartitionMat.txt" % (comp, qp)), "rb").read()
+            assert allf.count(b"\n") == F_ * per_frame and one.count(b"\n") == per_frame
+            # frame 5 of the long file: skip five frames' worth of lines
+            pos = 0
+            for _ in range(5 * per_frame):
+                pos = allf.index(b"\n", pos) + 1
+            assert allf[pos:pos + len(one)] == one, (comp, qp)
+    hor, ver, qt, dire = E_read(pm / "All_3840x2160_30_Luma_QP32_PartitionMat.txt", F_, H_, W_)
+    assert hor[:, ::16, :].all() and ver[:, :, ::16].all()  # block borders are edges in every frame
+    assert qt.max() <= 3 and set(np.unique(dire)) <= {-1, 0, 1}
+
+
+def E_read(path, frames, height, width):
+    from pmp_vvc_tip2023_amd import engine as E
+    return E.read_partition_file(str(path), frames, height, width)
+
+
 def test_end_to_end_flags_vs_reference_logits(eng, g1, oracle_lib):
     """End-to-end audit ('bit-exact flags is only well-defined for identical logits'): split flags
     from the HIP path (own logits) against flags the oracle derives from the REFERENCE's logits (G1/G2, torch CPU).
