@@ -490,6 +490,26 @@ def test_config4_4k_frame_sharded_equals_unsharded(eng, oracle_lib):
         assert h.reshape(33, 60, 16, 16)[:, :, 0, :].all() and vv.reshape(33, 60, 16, 16)[:, :, :, 0].all()
 
 
+def test_driver_sequence_without_a_full_block(tmp_path):
+    """A sequence smaller than one 64x64 block (the reference's (H // 64) * (W // 64) = 0, Inference_QBD.py:125-129 cuts nothing):
+    the driver writes EMPTY PartitionMat files - what get_sequence_partition_for_VTM's loops produce for zero rows - and does not fail."""
+    import os
+    from pmp_vvc_tip2023_amd import inference_qbd as D
+    inp = tmp_path / "in"; cfg = tmp_path / "cfg"
+    inp.mkdir(); cfg.mkdir()
+    w, h, fr = 96, 48, 2
+    with open(inp / "Small_96x48_30.yuv", "wb") as f:
+        f.write(bytes(fr * w * h * 3 // 2))
+    (inp / "table.txt").write_text("Small,Small_96x48_30.yuv,%d,%d,%d,30\n#end!!!!\n" % (w, h, fr))
+    (cfg / "Small.cfg").write_text("InputFile : Small_96x48_30.yuv\nInputBitDepth : 8\n")
+    D.main(["--jobID", "s", "--inputDir", str(inp), "--outDir", str(tmp_path / "o"), "--seqTable", "table.txt", "--cfgDir", str(cfg),
+            "--ssRatio", "1", "--seqNum", "1", "--qps", "22", "--allowSyntheticMTT", "--binary"])
+    pm = tmp_path / "o" / "s" / "PartitionMat"
+    for comp in ("Luma", "Chroma"):
+        assert os.path.getsize(pm / ("Small_96x48_30_%s_QP22_PartitionMat.txt" % comp)) == 0
+        assert os.path.getsize(pm / ("Small_96x48_30_%s_QP22_PartitionMat.pmpb" % comp)) == 40      # header only
+
+
 def test_config4_eight_4k_frames_all_qps_through_the_driver(tmp_path):
     """BASELINE.json configs[3]'s input on the one GPU of the test box: 8 synthetic 3840x2160 frames, Luma + Chroma x 4 QPs through the
     CLI driver (device-resident blocks, packed records, writer threads).  Every file has the geometry the VTM parser expects
