@@ -119,6 +119,9 @@ def build_parser():
     p.add_argument("--qps", default="22,27,32,37")
     p.add_argument("--comps", default="Luma,Chroma")
     p.add_argument("--device", default=None, type=int, help="GPU index (default: LOCAL_RANK)")
+    p.add_argument("--gpus", default=1, type=int,
+                   help="shard every sequence's blocks over this many GPUs of the node: started without a launcher the driver spawns "
+                        "its own rank processes (one per GPU, RCCL gather of the records to rank 0); under torchrun it is one rank")
     p.add_argument("--binary", action="store_true", help="also write <name>_PartitionMat.pmpb (binary side channel, include/pmp.h)")
     p.add_argument("--strictBatch", action="store_true",
                    help="run exactly --batchSize blocks per pass (default: the library's 4096-block chunk; same results)")
@@ -317,8 +320,39 @@ def inference_VVC_seqs(args):
         dist.destroy_process_group()
 
 
+def launch_ranks(n, argv):
+    """`--gpus N` without a launcher: N fresh rank processes (the parent makes no GPU call), exit code = first failure."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    procs = [subprocess.Popen([sys.executable, "-m", "pmp_vvc_tip2023_amd.inference_qbd"] + list(argv), env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
+             for r in range(n)]
+    rc = 0
+    try:
+        for p in procs:
+            p.wait()
+            rc = rc or p.returncode
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
     args = build_parser().parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        rc = launch_ranks(args.gpus, argv)
+        if rc:
+            raise SystemExit(rc)
+        return
     t0 = time.time()
     inference_VVC_seqs(args)
     print("Total inference time:", time.time() - t0)

@@ -46,7 +46,7 @@ def test_cli_flags_match_reference_defaults():
 def test_cli_extension_flags_default_to_reference_behaviour():
     """Flags this driver adds are off by default; with them the output contract is unchanged (tests/test_gpu_parity.py)."""
     a = D.build_parser().parse_args([])
-    assert a.binary is False and a.hostBlocks is False and a.strictBatch is False and a.device is None
+    assert a.binary is False and a.hostBlocks is False and a.strictBatch is False and a.device is None and a.gpus == 1
     assert a.qps == "22,27,32,37" and a.comps == "Luma,Chroma"
     b = D.build_parser().parse_args(["--hostBlocks", "--strictBatch", "--binary", "--batchSize", "7", "--qps", "22", "--comps", "Chroma"])
     assert b.hostBlocks and b.strictBatch and b.binary and b.batchSize == 7 and b.qps == "22" and b.comps == "Chroma"

@@ -606,6 +606,16 @@ def test_driver_two_ranks_equal_one_rank(tmp_path):
     assert len(names) == 4 and names == sorted(os.listdir(d2))
     for nme in names:
         assert open(d1 / nme, "rb").read() == open(d2 / nme, "rb").read(), nme
+    # the driver as its own launcher: --gpus 2 with no WORLD_SIZE in the environment spawns the two ranks itself
+    env3 = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env3.update(PMP_DIST_BACKEND="gloo", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-m", "pmp_vvc_tip2023_amd.inference_qbd", "--jobID", "three", "--outDir", str(tmp_path / "o3"), "--gpus", "2"] + common,
+                       env=env3, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d3 = tmp_path / "o3" / "three" / "PartitionMat"
+    assert names == sorted(os.listdir(d3))
+    for nme in names:
+        assert open(d1 / nme, "rb").read() == open(d3 / nme, "rb").read(), nme
 
 
 # ------------------------------------------------------------------------------------------------ bench.py contract
