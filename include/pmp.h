@@ -165,6 +165,23 @@ int pmp_write_partition_file(const char *path, int frames, int height, int width
 int64_t pmp_format_partition_text(int frames, int height, int width, const uint8_t *hor, const uint8_t *ver,
                                   const uint8_t *qt_u8, const int8_t *dire_i8, char *buf, int64_t cap);
 
+/* ---- sharded emission (the reference's serial tail is the per-value text emission, Map2Partition.py:401-412).
+ *      Frames are self-contained in the file (Map2Partition.py:389-412) and inside a frame every section (hor, ver, qt, dire 0..2) is
+ *      row-major, so a writer that holds `block_rows` consecutive BLOCK ROWS of one frame (block_rows * (width/64) blocks, row-major)
+ *      owns six contiguous byte ranges of the file.  These two calls produce them back to back - section-major, i.e. exactly the
+ *      text of a frame of height 64*block_rows - and report the exact size of every (block row, section) pair in
+ *      row_section_bytes[block_rows][6] (may be NULL), from which the ranks derive their file offsets with one exclusive scan
+ *      (pmp_vvc_tip2023_amd/parallel.py: section_offsets) and write concurrently with pwrite.  buf == NULL: sizes only; the return
+ *      value is the total byte count.  The _records form reads packed PMP_RECORD_BYTES records, what the device path produces. ---- */
+int64_t pmp_format_partition_rows(int width, int block_rows, const uint8_t *hor, const uint8_t *ver, const uint8_t *qt_u8,
+                                  const int8_t *dire_i8, char *buf, int64_t cap, int64_t *row_section_bytes);
+int64_t pmp_format_partition_rows_records(int width, int block_rows, const uint8_t *rec, char *buf, int64_t cap,
+                                          int64_t *row_section_bytes);
+/* The same rows as matrices (binary side channel / in-process hand-over): hor, ver u8[16*block_rows][cols], qt u8[8*block_rows][cols/2],
+ * dire i8[3][16*block_rows][cols], cols = 16*(width>>6). */
+int pmp_tile_partition_rows_records(int width, int block_rows, const uint8_t *rec, uint8_t *out_hor, uint8_t *out_ver, uint8_t *out_qt,
+                                    int8_t *out_dire);
+
 /* ---- binary side channel.  Same content as the text file, laid out as the arrays the patched VTM keeps
  *      after parsing (Lib/CommonLib/Rom.h:240-248), so a consumer can mmap it instead of 645 k getline+stoi calls per frame:
  *        char magic[8] = "PMPB1\0\0\0"; int32 frames, height, width, rows (= 16*(H>>6)), cols (= 16*(W>>6)), reserved[3];

@@ -9,6 +9,7 @@ ABL_LIB_PATH = os.path.join(_HERE, "libpmp_hip_abl.so")            # make abl: m
 HOSTASAN_LIB_PATH = os.path.join(_HERE, "libpmp_hostasan.so")      # make hostasan: host-only units under ASan/UBSan (tests only)
 
 PMP_LUMA, PMP_CHROMA = 0, 1
+PMP_RECORD_BYTES = 1344
 NET_IDS = {"Luma_Q": 0, "Luma_MSBD": 1, "Chroma_Q": 2, "Chroma_MSBD": 3}
 ERRORS = {-1: "PMP_E_INVALID", -2: "PMP_E_HIP", -3: "PMP_E_NOWEIGHTS", -4: "PMP_E_IO", -5: "PMP_E_NOMEM", -6: "PMP_E_NODEVICE", -7: "PMP_E_RANGE"}
 
@@ -58,6 +59,9 @@ SIGNATURES = {
     "pmp_write_partition_binary": (_I, [C.c_char_p, _I, _I, _I, _VP, _VP, _VP, _VP]),
     "pmp_tile_partition_maps": (_I, [_I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "pmp_format_partition_text": (_I64, [_I, _I, _I, _VP, _VP, _VP, _VP, _VP, _I64]),
+    "pmp_format_partition_rows": (_I64, [_I, _I, _VP, _VP, _VP, _VP, _VP, _I64, _VP]),
+    "pmp_format_partition_rows_records": (_I64, [_I, _I, _VP, _VP, _I64, _VP]),
+    "pmp_tile_partition_rows_records": (_I, [_I, _I, _VP, _VP, _VP, _VP, _VP]),
     "pmp_ktime_enable": (_I, [_VP, _U32]),
     "pmp_ktime_classes": (_I, []),
     "pmp_ktime_name": (C.c_char_p, [_I]),

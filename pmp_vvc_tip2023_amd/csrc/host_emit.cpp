@@ -63,11 +63,110 @@ static inline char *emit_i8_row(char *p, const int8_t *v, int count)
     return p;
 }
 
+}  // extern "C" (reopened below)
+
+namespace {
+
+// Per-block arrays seen through byte strides: the four dense arrays of the classic entry points (strides 256/256/64/768) or the
+// fields of packed 1344-byte records (PMP_RECORD_BYTES: hor | ver | qt | dire), which is what the multi-GPU path holds.
+struct BlockView {
+    const uint8_t *hor, *ver, *qt;
+    const int8_t *dire;
+    int64_t sh, sv, sq, sd;
+};
+
+inline int64_t u8_len(const uint8_t *v, int n)
+{
+    int64_t len = 2 * n;
+    for (int i = 0; i < n; ++i) len += (v[i] >= 10) + (v[i] >= 100);
+    return len;
+}
+
+inline int64_t i8_len(const int8_t *v, int n)
+{
+    int64_t len = 2 * n;
+    for (int i = 0; i < n; ++i) { const int d = v[i], a = d < 0 ? -d : d; len += (d < 0) + (a >= 10) + (a >= 100); }
+    return len;
+}
+
+// Exact text size of the six sections (hor, ver, qt, dire 0..2) of ONE block row of `bw` blocks starting at block `b0`.
+void row_section_sizes(const BlockView &v, int64_t b0, int bw, int64_t out[6])
+{
+    for (int k = 0; k < 6; ++k) out[k] = 0;
+    for (int bx = 0; bx < bw; ++bx) {
+        const int64_t b = b0 + bx;
+        out[0] += u8_len(v.hor + b * v.sh, 256);
+        out[1] += u8_len(v.ver + b * v.sv, 256);
+        out[2] += u8_len(v.qt + b * v.sq, 64);
+        for (int k = 0; k < 3; ++k) out[3 + k] += i8_len(v.dire + b * v.sd + k * 256, 256);
+    }
+}
+
+// Text of `nbr` consecutive block rows (bw blocks each, first block b0) in the file's order INSIDE a frame - section-major: all hor
+// matrix rows, all ver rows, the qt rows, then the three dire matrices (Map2Partition.py:401-412).  A whole frame is nbr = H/64.
+// A row of 16 values is at most 16 * 5 bytes.  Rows are written straight into the buffer while that much room is left; the last
+// rows of an exactly-sized buffer go through a bounce buffer, so `cap == size` is enough and never overrun.
+bool format_rows(const BlockView &v, int64_t b0, int nbr, int bw, char *&p, char *end)
+{
+    bool ok = true;
+    auto put_u8 = [&](const uint8_t *src, int count) {
+        if (end - p >= 80) { p = emit_u8_row(p, src, count); return; }
+        char tmp[96];
+        const size_t len = (size_t)(emit_u8_row(tmp, src, count) - tmp);
+        if ((size_t)(end - p) < len) { ok = false; return; }
+        memcpy(p, tmp, len);
+        p += len;
+    };
+    auto put_i8 = [&](const int8_t *src, int count) {
+        if (end - p >= 80) { p = emit_i8_row(p, src, count); return; }
+        char tmp[96];
+        const size_t len = (size_t)(emit_i8_row(tmp, src, count) - tmp);
+        if ((size_t)(end - p) < len) { ok = false; return; }
+        memcpy(p, tmp, len);
+        p += len;
+    };
+    const int R = 16 * nbr;
+    for (int plane = 0; plane < 2; ++plane) {
+        const uint8_t *src = plane ? v.ver : v.hor;
+        const int64_t st = plane ? v.sv : v.sh;
+        for (int r = 0; r < R && ok; ++r)
+            for (int bx = 0; bx < bw && ok; ++bx) put_u8(src + (b0 + (int64_t)(r >> 4) * bw + bx) * st + (r & 15) * 16, 16);
+    }
+    for (int r = 0; r < R / 2 && ok; ++r)
+        for (int bx = 0; bx < bw && ok; ++bx) put_u8(v.qt + (b0 + (int64_t)(r >> 3) * bw + bx) * v.sq + (r & 7) * 8, 8);
+    for (int k = 0; k < 3; ++k)
+        for (int r = 0; r < R && ok; ++r)
+            for (int bx = 0; bx < bw && ok; ++bx) put_i8(v.dire + (b0 + (int64_t)(r >> 4) * bw + bx) * v.sd + k * 256 + (r & 15) * 16, 16);
+    return ok;
+}
+
+int64_t format_block_rows(const char *who, int W, int nbr, const BlockView &v, char *buf, int64_t cap, int64_t *row_bytes)
+{
+    if (W < 0 || nbr < 0 || !v.hor || !v.ver || !v.qt || !v.dire) return set_err_global(PMP_E_INVALID, std::string(who) + ": bad arguments");
+    const int bw = W / 64;
+    int64_t total = 0;
+    if (row_bytes || !buf) {
+        for (int r = 0; r < nbr; ++r) {
+            int64_t sz[6];
+            row_section_sizes(v, (int64_t)r * bw, bw, sz);
+            for (int k = 0; k < 6; ++k) { total += sz[k]; if (row_bytes) row_bytes[r * 6 + k] = sz[k]; }
+        }
+        if (!buf) return total;
+    }
+    char *p = buf;
+    if (!format_rows(v, 0, nbr, bw, p, buf + cap)) return set_err_global(PMP_E_INVALID, std::string(who) + ": buffer too small");
+    return p - buf;
+}
+
+}  // namespace
+
+extern "C" {
+
 int64_t pmp_format_partition_text(int frames, int H, int W, const uint8_t *hor, const uint8_t *ver, const uint8_t *qt_u8,
                                   const int8_t *dire, char *buf, int64_t cap)
 {
     if (frames < 0 || H < 0 || W < 0 || !hor || !ver || !qt_u8 || !dire) return set_err(nullptr, PMP_E_INVALID, "pmp_format_partition_text: bad arguments");
-    const int bh = H / 64, bw = W / 64, R = 16 * bh;
+    const int bh = H / 64, bw = W / 64;
     const int64_t nblk = (int64_t)frames * bh * bw;
     if (!buf) {   // exact size: 2 bytes per value, +1 per negative direction, +digits beyond one for values >= 10
         int64_t need = nblk * (256 + 256 + 64 + 768) * 2, neg = 0;
@@ -84,42 +183,25 @@ int64_t pmp_format_partition_text(int frames, int H, int W, const uint8_t *hor, 
         }
         return need;
     }
-    // A row of 16 values is at most 16 * 5 bytes.  Rows are written straight into the buffer while that much room is left;
-    // the last rows of an exactly-sized buffer go through a bounce buffer, so `cap == size` is enough and never overrun.
+    const BlockView v{hor, ver, qt_u8, dire, 256, 256, 64, 768};
     char *p = buf, *end = buf + cap;
-    bool ok = true;
-    auto put_u8 = [&](const uint8_t *v, int count) {
-        if (end - p >= 80) { p = emit_u8_row(p, v, count); return; }
-        char tmp[96];
-        const size_t len = (size_t)(emit_u8_row(tmp, v, count) - tmp);
-        if ((size_t)(end - p) < len) { ok = false; return; }
-        memcpy(p, tmp, len);
-        p += len;
-    };
-    auto put_i8 = [&](const int8_t *v, int count) {
-        if (end - p >= 80) { p = emit_i8_row(p, v, count); return; }
-        char tmp[96];
-        const size_t len = (size_t)(emit_i8_row(tmp, v, count) - tmp);
-        if ((size_t)(end - p) < len) { ok = false; return; }
-        memcpy(p, tmp, len);
-        p += len;
-    };
-    for (int f = 0; f < frames && ok; ++f) {
-        const int64_t base = (int64_t)f * bh * bw;
-        for (int plane = 0; plane < 2; ++plane) {
-            const uint8_t *src = plane ? ver : hor;
-            for (int r = 0; r < R && ok; ++r)
-                for (int bx = 0; bx < bw && ok; ++bx) put_u8(src + (base + (int64_t)(r >> 4) * bw + bx) * 256 + (r & 15) * 16, 16);
-        }
-        for (int r = 0; r < R / 2 && ok; ++r)
-            for (int bx = 0; bx < bw && ok; ++bx) put_u8(qt_u8 + (base + (int64_t)(r >> 3) * bw + bx) * 64 + (r & 7) * 8, 8);
-        for (int k = 0; k < 3; ++k)
-            for (int r = 0; r < R && ok; ++r)
-                for (int bx = 0; bx < bw && ok; ++bx)
-                    put_i8(dire + (base + (int64_t)(r >> 4) * bw + bx) * 768 + k * 256 + (r & 15) * 16, 16);
-    }
-    if (!ok) return set_err(nullptr, PMP_E_INVALID, "pmp_format_partition_text: buffer too small");
+    for (int f = 0; f < frames; ++f)
+        if (!format_rows(v, (int64_t)f * bh * bw, bh, bw, p, end)) return set_err(nullptr, PMP_E_INVALID, "pmp_format_partition_text: buffer too small");
     return p - buf;
+}
+
+int64_t pmp_format_partition_rows(int W, int block_rows, const uint8_t *hor, const uint8_t *ver, const uint8_t *qt_u8, const int8_t *dire,
+                                  char *buf, int64_t cap, int64_t *row_section_bytes)
+{
+    const BlockView v{hor, ver, qt_u8, dire, 256, 256, 64, 768};
+    return format_block_rows("pmp_format_partition_rows", W, block_rows, v, buf, cap, row_section_bytes);
+}
+
+int64_t pmp_format_partition_rows_records(int W, int block_rows, const uint8_t *rec, char *buf, int64_t cap, int64_t *row_section_bytes)
+{
+    const BlockView v{rec, rec ? rec + 256 : nullptr, rec ? rec + 512 : nullptr, rec ? reinterpret_cast<const int8_t *>(rec + 576) : nullptr,
+                      PMP_RECORD_BYTES, PMP_RECORD_BYTES, PMP_RECORD_BYTES, PMP_RECORD_BYTES};
+    return format_block_rows("pmp_format_partition_rows_records", W, block_rows, v, buf, cap, row_section_bytes);
 }
 
 int pmp_write_partition_file(const char *path, int frames, int H, int W, const uint8_t *hor, const uint8_t *ver,
@@ -177,27 +259,52 @@ int pmp_write_partition_binary(const char *path, int frames, int H, int W, const
     return PMP_OK;
 }
 
+}  // extern "C" (reopened below)
+
+namespace {
+
+// Frame matrices of `nbr` block rows (first block b0): hor, ver u8[16 nbr][C], qt u8[8 nbr][C/2], dire i8[3][16 nbr][C].
+void tile_rows(const BlockView &v, int64_t b0, int nbr, int bw, uint8_t *oh, uint8_t *ov, uint8_t *oq, int8_t *od)
+{
+    const int R = 16 * nbr, C = 16 * bw;
+    for (int r = 0; r < R; ++r)
+        for (int bx = 0; bx < bw; ++bx) {
+            const int64_t blk = b0 + (int64_t)(r >> 4) * bw + bx;
+            const int cell = (r & 15) * 16;
+            const int64_t o = (int64_t)r * C + bx * 16;
+            memcpy(oh + o, v.hor + blk * v.sh + cell, 16);
+            memcpy(ov + o, v.ver + blk * v.sv + cell, 16);
+            for (int k = 0; k < 3; ++k) memcpy(od + (int64_t)k * R * C + o, v.dire + blk * v.sd + k * 256 + cell, 16);
+        }
+    for (int r = 0; r < R / 2; ++r)
+        for (int bx = 0; bx < bw; ++bx)
+            memcpy(oq + (int64_t)r * (C / 2) + bx * 8, v.qt + (b0 + (int64_t)(r >> 3) * bw + bx) * v.sq + (r & 7) * 8, 8);
+}
+
+}  // namespace
+
+extern "C" {
+
 int pmp_tile_partition_maps(int frames, int H, int W, const uint8_t *hor, const uint8_t *ver, const uint8_t *qt_u8,
                             const int8_t *dire, uint8_t *out_hor, uint8_t *out_ver, uint8_t *out_qt, int8_t *out_dire)
 {
     if (frames < 0 || H < 0 || W < 0 || !hor || !ver || !qt_u8 || !dire || !out_hor || !out_ver || !out_qt || !out_dire)
         return set_err(nullptr, PMP_E_INVALID, "pmp_tile_partition_maps: bad arguments");
-    const int bh = H / 64, bw = W / 64, R = 16 * bh, C = 16 * bw;
-    for (int f = 0; f < frames; ++f) {
-        const int64_t base = (int64_t)f * bh * bw;
-        for (int r = 0; r < R; ++r)
-            for (int cc = 0; cc < C; ++cc) {
-                const int64_t blk = base + (r >> 4) * bw + (cc >> 4);
-                const int cell = (r & 15) * 16 + (cc & 15);
-                const int64_t o = ((int64_t)f * R + r) * C + cc;
-                out_hor[o] = hor[blk * 256 + cell];
-                out_ver[o] = ver[blk * 256 + cell];
-                for (int k = 0; k < 3; ++k) out_dire[(((int64_t)f * 3 + k) * R + r) * C + cc] = dire[blk * 768 + k * 256 + cell];
-            }
-        for (int r = 0; r < R / 2; ++r)
-            for (int cc = 0; cc < C / 2; ++cc)
-                out_qt[((int64_t)f * (R / 2) + r) * (C / 2) + cc] = qt_u8[(base + (r >> 3) * bw + (cc >> 3)) * 64 + (r & 7) * 8 + (cc & 7)];
-    }
+    const int bh = H / 64, bw = W / 64;
+    const int64_t R = 16 * bh, C = 16 * bw;
+    const BlockView v{hor, ver, qt_u8, dire, 256, 256, 64, 768};
+    for (int f = 0; f < frames; ++f)
+        tile_rows(v, (int64_t)f * bh * bw, bh, bw, out_hor + f * R * C, out_ver + f * R * C, out_qt + f * (R / 2) * (C / 2), out_dire + f * 3 * R * C);
+    return PMP_OK;
+}
+
+int pmp_tile_partition_rows_records(int W, int block_rows, const uint8_t *rec, uint8_t *out_hor, uint8_t *out_ver, uint8_t *out_qt, int8_t *out_dire)
+{
+    if (W < 0 || block_rows < 0 || !rec || !out_hor || !out_ver || !out_qt || !out_dire)
+        return set_err(nullptr, PMP_E_INVALID, "pmp_tile_partition_rows_records: bad arguments");
+    const BlockView v{rec, rec + 256, rec + 512, reinterpret_cast<const int8_t *>(rec + 576), PMP_RECORD_BYTES, PMP_RECORD_BYTES, PMP_RECORD_BYTES,
+                      PMP_RECORD_BYTES};
+    tile_rows(v, 0, block_rows, W / 64, out_hor, out_ver, out_qt, out_dire);
     return PMP_OK;
 }
 

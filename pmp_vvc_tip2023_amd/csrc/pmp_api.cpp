@@ -375,6 +375,7 @@ int pmp_infer_postprocess_device(pmp_ctx *c, int comp, int qp, const uint8_t *by
 // ---- packed records: hor[256] | ver[256] | qt[64] | dire[768] per block, the unit of the multi-GPU gather ------------
 static int post_records(pmp_ctx *c, int comp, const float *qt, const float *bt, const float *dire, int64_t n, uint8_t *rec)
 {
+    if (n == 0) return PMP_OK;   // an empty shard: torch.empty((0, 1344)).data_ptr() is 0, as for the four-array entry points
     if (!rec || (reinterpret_cast<uintptr_t>(rec) & 3)) return set_err(c, PMP_E_INVALID, "records: null or unaligned (4 bytes) buffer");
     return post_device_impl(c, comp, qt, bt, dire, n, rec, rec + 256, rec + 512, reinterpret_cast<int8_t *>(rec + 576), PMP_RECORD_BYTES);
 }
@@ -389,6 +390,7 @@ int pmp_infer_postprocess_records_device(pmp_ctx *c, int comp, int qp, const uin
                                          int64_t n, uint8_t *rec)
 {
     CHECK_CTX(c);
+    if (n == 0) return PMP_OK;   // an empty shard has no buffers at all
     int rc;
     if ((rc = ensure(c, c->d_logit[0], (size_t)(n ? n : 1) * 64 * 4)) || (rc = ensure(c, c->d_logit[1], (size_t)(n ? n : 1) * 768 * 4)) ||
         (rc = ensure(c, c->d_logit[2], (size_t)(n ? n : 1) * 768 * 4)))

@@ -34,14 +34,21 @@ struct Scan {
         ++p;
         return true;
     }
-    bool integer(long long &v)
+    bool integer(long long &v)   // bounded by `end` (the manifest is not NUL-terminated) and by 18 digits (no overflow)
     {
         ws();
-        char *e = nullptr;
-        if (p >= end || !((*p >= '0' && *p <= '9') || *p == '-')) return false;
-        v = strtoll(p, &e, 10);
-        if (e == p || e > end) return false;
-        p = e;
+        const char *q = p;
+        bool neg = false;
+        if (q < end && *q == '-') { neg = true; ++q; }
+        if (q >= end || *q < '0' || *q > '9') return false;
+        long long acc = 0;
+        int digits = 0;
+        while (q < end && *q >= '0' && *q <= '9') {
+            if (++digits > 18) return false;
+            acc = acc * 10 + (*q++ - '0');
+        }
+        v = neg ? -acc : acc;
+        p = q;
         return true;
     }
     bool skip_value()   // any JSON value
@@ -126,9 +133,12 @@ int read_pmpw(const char *path, WeightFile &wf)
                             if (!s.lit('}')) return bad("tensor entry end");
                             break;
                         }
-                        long long cnt = 1;
-                        for (int i = 0; i < t.ndim; ++i) cnt *= t.shape[i];
-                        if (t.name.empty() || !have_off || t.offset + cnt > (long long)nfl) return bad("tensor outside the payload");
+                        long long cnt = 1;   // bounded while multiplying: four dimensions of up to 2^24 would overflow 64 bits
+                        for (int i = 0; i < t.ndim; ++i) {
+                            cnt *= t.shape[i];
+                            if (cnt > (long long)nfl) return bad("tensor outside the payload");
+                        }
+                        if (t.name.empty() || !have_off || t.offset > (long long)nfl - cnt) return bad("tensor outside the payload");
                         wf.tensors.push_back(t);
                         if (s.lit(',')) continue;
                         if (!s.lit(']')) return bad("tensors end");

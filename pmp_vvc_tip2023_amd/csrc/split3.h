@@ -62,14 +62,20 @@ __device__ __forceinline__ void split2(float v, _Float16 &a, _Float16 &b)
 
 // Saturation tracking (pmp_get_saturation, include/pmp.h): every kernel that writes split-2 planes keeps the largest |value|
 // it stores and raises the context's sticky flag when the clamp above fired for any of them.
+// The maximum is taken on the magnitudes' BIT PATTERNS as unsigned integers: ordered like the floats for finite values and
+// infinities, and a NaN (exponent all ones, non-zero mantissa) ranks above them all - so a NaN activation raises the flag too
+// (fmaxf would drop it and `NaN > 65504.f` is false).
+__device__ __forceinline__ unsigned sat_bits(float x) { return __float_as_uint(x) & 0x7fffffffu; }
+
 __device__ __forceinline__ float sat_amax4(float m, f32x4 v)
 {
-    return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    const unsigned a = max(sat_bits(v.x), sat_bits(v.y)), b = max(sat_bits(v.z), sat_bits(v.w));
+    return __uint_as_float(max(max(sat_bits(m), a), b));
 }
 
 __device__ __forceinline__ void sat_report(unsigned *flag, float amax)
 {
-    if (flag && amax > 65504.f) atomicOr(flag, 1u);
+    if (flag && sat_bits(amax) > 0x477fe000u) atomicOr(flag, 1u);   // 0x477fe000 = 65504.f; true for NaN as well
 }
 
 __device__ __forceinline__ f32x4 load_split2_4(const unsigned short *p, size_t plane_stride)

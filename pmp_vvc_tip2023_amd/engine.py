@@ -300,6 +300,36 @@ def format_partition_text(frames, height, width, hor, ver, qt_u8, dire_i8):
     return buf.raw[:need]
 
 
+def format_partition_rows_records(width, block_rows, rec):
+    """Text of `block_rows` consecutive block rows of one frame from packed records u8[block_rows * (width // 64), 1344]
+    (pmp_format_partition_rows_records): -> (ctypes char buffer holding the six sections back to back, int64[block_rows, 6] exact
+    byte count of every (block row, section)).  Host-only; the C formatter releases the GIL."""
+    lib = _lib.load()
+    rec = np.ascontiguousarray(rec, np.uint8)
+    bw = int(width) // 64
+    if rec.size != int(block_rows) * bw * _lib.PMP_RECORD_BYTES:
+        raise ValueError("format_partition_rows_records: %d bytes of records for %d block rows of %d blocks" % (rec.size, block_rows, bw))
+    sizes = np.zeros((int(block_rows), 6), np.int64)
+    need = _lib.check(lib.pmp_format_partition_rows_records(int(width), int(block_rows), _ptr(rec), None, 0, _ptr(sizes)))
+    buf = C.create_string_buffer(max(int(need), 1))
+    got = _lib.check(lib.pmp_format_partition_rows_records(int(width), int(block_rows), _ptr(rec), buf, need, None))
+    assert got == need == int(sizes.sum())
+    return buf, sizes
+
+
+def tile_partition_rows_records(width, block_rows, rec):
+    """The same rows as matrices: hor, ver u8[16 n, C], qt u8[8 n, C/2], dire i8[3, 16 n, C] (pmp_tile_partition_rows_records)."""
+    lib = _lib.load()
+    rec = np.ascontiguousarray(rec, np.uint8)
+    R, Cc = 16 * int(block_rows), 16 * (int(width) // 64)
+    if rec.size != int(block_rows) * (Cc // 16) * _lib.PMP_RECORD_BYTES:
+        raise ValueError("tile_partition_rows_records: record count does not match the geometry")
+    oh = np.zeros((R, Cc), np.uint8); ov = np.zeros_like(oh); oq = np.zeros((R // 2, Cc // 2), np.uint8); od = np.zeros((3, R, Cc), np.int8)
+    if rec.size:
+        _lib.check(lib.pmp_tile_partition_rows_records(int(width), int(block_rows), _ptr(rec), _ptr(oh), _ptr(ov), _ptr(oq), _ptr(od)))
+    return oh, ov, oq, od
+
+
 def read_partition_file(path, frames, height, width):
     """Parser with the geometry rules of EncAppCfg::parsePartitionMatrix (EncAppCfg.cpp:4247-4250, :4299-4399):
     returns hor, ver [F,R,C], qt [F,R/2,C/2], dire [F,3,R,C] as int arrays (frame matrices, not per block)."""

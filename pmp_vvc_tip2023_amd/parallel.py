@@ -64,6 +64,21 @@ def init_process_group(device=None):
     return rank, world, local
 
 
+def all_reduce_sum(arr, device=None):
+    """Element-wise sum of an int64 numpy array over all ranks (every rank gets the result): the size table of the sharded
+    emission (emit.py).  RCCL moves a device tensor; gloo a CPU tensor."""
+    import torch
+    import torch.distributed as dist
+    a = np.ascontiguousarray(arr, np.int64)
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return a
+    t = torch.from_numpy(a.copy())
+    if dist.get_backend() == "nccl":
+        t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()
+
+
 def gather_records(local_rec, n_total, device=None):
     """Gather every rank's u8[n_r, 1344] records (rank order = block order) to rank 0.
 

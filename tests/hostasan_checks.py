@@ -120,6 +120,24 @@ def main():
     cases = {"empty": b"", "magic": b"PMPW2\n" + good[6:], "cut_manifest": good[:10 + jl // 2], "cut_payload": good[:10 + jl + 100],
              "huge_len": good[:6] + (2 ** 31).to_bytes(4, "little") + good[10:], "garbage_json": good[:10] + b"{" * jl + good[10 + jl:],
              "no_tensors": good[:6] + (2).to_bytes(4, "little") + b"{}" + good[10 + jl:]}
+
+    def crafted(manifest, payload=b""):
+        return b"PMPW1\n" + len(manifest).to_bytes(4, "little") + manifest + payload
+    big = 1 << 24
+    cases.update({
+        # four dimensions of 2^24: the element count would overflow 64 bits if it were not bounded while multiplying
+        "shape_overflow": crafted(b'{"net":"Luma_Q","qp":22,"tensors":[{"name":"a","shape":[%d,%d,%d,%d],"offset":0}]}' % (big, big, big, big), b"\0" * 64),
+        # offset + count wraps around
+        "offset_wrap": crafted(b'{"net":"Luma_Q","qp":22,"tensors":[{"name":"a","shape":[4],"offset":9223372036854775800}]}', b"\0" * 64),
+        "offset_19_digits": crafted(b'{"net":"Luma_Q","qp":22,"tensors":[{"name":"a","shape":[4],"offset":1000000000000000000000}]}', b"\0" * 64),
+        # the manifest ends in digits and nothing follows: an unbounded strtoll would read past the buffer
+        "digits_at_end": crafted(b'{"net":"Luma_Q","qp":2222222222'),
+        "digits_at_end2": crafted(b'{"tensors":[{"name":"a","shape":[1],"offset":12345'),
+        "last_element_ok_but_one_past": crafted(b'{"net":"Luma_Q","qp":22,"tensors":[{"name":"a","shape":[4],"offset":13}]}', b"\0" * 64),
+    })
+    ok = os.path.join(tmp, "edge_ok.pmpw")       # the last four floats of the payload: accepted
+    open(ok, "wb").write(crafted(b'{"net":"Luma_Q","qp":22,"tensors":[{"name":"a","shape":[4],"offset":12}]}', b"\0" * 64))
+    assert lib.pmp_debug_read_weights_file(ok.encode(), None, None, None, None, None) == 0
     for name, blob in cases.items():
         pth = os.path.join(tmp, name + ".pmpw")
         open(pth, "wb").write(blob)
