@@ -25,7 +25,8 @@
  *   - Layouts (all dense, row-major):  qt f32[n][8][8]; bt, dire f32[n][3][16][16] (layer-major, as
  *     Metrics.py:399-402 regroups the heads); hor, ver u8[n][16][16]; qt_u8 u8[n][8][8]; dire_i8 i8[n][3][16][16].
  *   - *_device variants take device pointers and run asynchronously on the context's stream
- *     (pmp_set_stream lets the caller supply it); the others take host pointers and synchronise.
+ *     (pmp_set_stream lets the caller supply it); the others take host pointers and synchronise.  pmp_synchronize makes the
+ *     outputs of every *_device call made so far final (see the range guard below).
  */
 #ifndef PMP_H
 #define PMP_H
@@ -90,13 +91,20 @@ int pmp_get_precision(const pmp_ctx *ctx);
 
 /* Range guard of the f16x3 datapath.  Its activations travel as two fp16 terms, so a value beyond +-65504 is clamped when it
  * is stored (the reference's nets stay below 3e3 on 8-bit content with the trained QT weights; trained MTT weights are not
- * in the reference checkout).  Every kernel that stores such a tensor raises a per-context device flag when the clamp fires.
- *   PMP_SAT_RERUN (default)  each pmp_infer* call waits for its passes, reads the flag, and if it fired runs the WHOLE call
- *                            again on the bf16x6 datapath (no range limit, fp32-equivalent): results are always right; the
- *                            *_device entry points therefore return with their work complete, not merely enqueued
- *   PMP_SAT_ERROR            same check, but the call returns PMP_E_RANGE instead of re-running
- *   PMP_SAT_IGNORE           no check and no synchronisation (the *_device calls stay asynchronous); the caller polls
- * pmp_get_saturation synchronises and returns 1 if any inference call of this context saturated since the last
+ * in the reference checkout).  Every kernel that stores such a tensor raises a per-context device flag when the clamp fires
+ * (a NaN raises it too).  Every pmp_infer* call snapshots the flag behind its passes - stream-ordered, into pinned host memory -
+ * and the snapshot is LOOKED AT LATER, so that the *_device entry points never stall the host: by the next call of the context
+ * (polled: only snapshots that have landed), and by pmp_synchronize / pmp_get_saturation / any host-pointer call (waited for).
+ *   PMP_SAT_RERUN (default)  a call whose flag fired is run AGAIN on the bf16x6 datapath (no range limit, fp32-equivalent) into
+ *                            the same output buffers, and every post-processing call that was enqueued after it is replayed in
+ *                            order.  Consequence for *_device callers: outputs are FINAL once pmp_synchronize (or
+ *                            pmp_get_saturation) has returned - synchronising the stream yourself is enough only if you also
+ *                            know the flag stayed down; inputs and outputs must stay untouched until then.  Host-pointer entry
+ *                            points return final results, as before.
+ *   PMP_SAT_ERROR            the call that looks at a fired snapshot returns PMP_E_RANGE (for *_device calls that may be the
+ *                            NEXT call or pmp_synchronize) and forgets the calls in flight; nothing is re-run
+ *   PMP_SAT_IGNORE           no snapshots, no re-runs; the caller polls
+ * pmp_get_saturation settles the calls in flight and returns 1 if any inference call of this context saturated since the last
  * pmp_clear_saturation (0 otherwise, negative on error); pmp_get_saturation_reruns counts the calls that were re-run. */
 #define PMP_SAT_RERUN 0
 #define PMP_SAT_ERROR 1
@@ -206,18 +214,11 @@ const char *pmp_ktime_name(int cls);
 /* Synchronises, then returns launches / total milliseconds / algorithmic FLOPs accumulated for the class. */
 int pmp_ktime_get(pmp_ctx *ctx, int cls, int64_t *launches, double *ms, double *flops);
 
-/* ---- measurement hook: selects the conv kernel build used by later launches (process-wide), for in-process A/B timing
- *      (tools/conv_ab.py).  Every variant this library accepts (0..9) computes bit-identical results per datapath
- *      (tests/test_gpu_parity.py::test_f16x3_conv_variants_agree); the timing-only builds that do not (10 and above) exist only in
- *      the measurement library libpmp_hip_abl.so (make abl) and are rejected here.
- *      fp32 datapath: 0 = un-pipelined kernel, 1 = software-pipelined (3 waves/SIMD), 2 = fully pipelined, 2 waves/SIMD (default).
- *      f16x3 datapath, Cout = 64 kernels (conv_f16x3.hip; anything else = the default: three workgroups per CU, 168 VGPRs):
- *        1 = the 32-channel-shortcut instantiations at three workgroups per CU (measures the same as their default two)
- *        3 = two workgroups per CU (236-256 VGPRs, 8-row pixel fragments)     4 = that form made persistent
- *        5 = the default form made persistent (3x3 only)                       6 = loader-wave form (fifth wave fills the halo by LDS-DMA)
- *        7 = 512-thread workgroups                                             8 = 16-row x 1-cout-group wave tiles (3x3 only)
- *        9 = 32x16 tiles, 64-cout wave tiles, LDS-DMA, hand-counted vmcnt (conv_f16x3_t32.hip; 3x3 64->64 only)
- *      All of them measured slower than (or equal to) the default: DESIGN.md 4.1a. ---- */
+/* ---- measurement hook.  The product library ships ONE form of every convolution kernel - number 2 - and accepts nothing else
+ *      here (PMP_E_INVALID): it has no process-wide kernel selector.  The forms that were built, parity-tested and measured slower
+ *      than or equal to the shipped ones (1, 3..9; bit-identical results) and the timing-only builds (10 and above; WRONG results)
+ *      exist only in the measurement library libpmp_hip_abl.so (`make abl`), where this call selects them process-wide for
+ *      in-process A/B timing (tools/conv_ab.py, tools/variants_agree.py; the list is in conv_f16x3.hip, the numbers in DESIGN.md 4.1a). ---- */
 int pmp_debug_set_conv_variant(int variant);
 
 /* ---- test hook (host only, no GPU needed): the f16x3 weight packing of one OIHW conv tensor (conv_f16x3.hip).

@@ -498,6 +498,7 @@ __global__ __launch_bounds__(W8 == 1 ? 512 : 256, W8 == 1 ? 4 : (NT == 4 && !LEA
     }
 }
 
+#ifdef PMP_ABLATION   // A/B forms that lost their measurement: built into libpmp_hip_abl.so only (make abl)
 // Persistent form of the same kernel for the Cout = 64 layers without a shortcut source and with an even group count: 2
 // workgroups per CU walk the tiles of their XCD's contiguous share.  The last channel group of a tile requests the first
 // group of the workgroup's next tile and the weight stream wraps around, so a tile starts at its first MFMA: no dispatch
@@ -616,6 +617,8 @@ __global__ __launch_bounds__(320, 3) void conv_h2_ld_kernel(ConvX6Args a)
     }
     h2_epilogue<4, 0, 3>(a, acc, n, ty, tx);
 }
+
+#endif   // PMP_ABLATION
 
 template <int NT, int ABL, int W8>
 __device__ __forceinline__ void h2_epilogue(const ConvX6Args &a, f32x4 (&acc)[WaveTile<NT, W8>::RW][WaveTile<NT, W8>::CW], int n, int ty, int tx)
@@ -739,92 +742,113 @@ __device__ __forceinline__ void h2_epilogue(const ConvX6Args &a, f32x4 (&acc)[Wa
     if (!a.out_f32) sat_report(a.sat, amax);   // fp32 outputs are not clamped
 }
 
+// The 1x1 shortcut source is a separate instantiation: its extra live state would spill in the common kernel.
+#define PMP_H2_LAUNCH(NT)                                                                                          \
+    if (a.x_sc) hipLaunchKernelGGL((conv_h2_kernel<KH, KW, NT, true>), dim3(grid), dim3(256), 0, s, a);           \
+    else hipLaunchKernelGGL((conv_h2_kernel<KH, KW, NT, false>), dim3(grid), dim3(256), 0, s, a)
+
+#ifdef PMP_ABLATION
+// Measurement library only (make abl -> libpmp_hip_abl.so; tools/conv_ab.py, tools/variants_agree.py, tools/conv_x6_bench.py):
+// the forms of the Cout = 64 kernels that were built, parity-tested and measured slower than or equal to the shipped ones
+// (g_conv_variant 1, 3..8: bit-identical results), and the timing-only builds (>= 10: WRONG results).  Returns true if it launched.
+//   1 = the 32-channel-shortcut instantiations at three workgroups per CU     3 = two workgroups per CU (236-256 VGPRs) / general shortcut pass
+//   4 = the two-workgroup form made persistent    5 = the default form made persistent (3x3)    6 = loader-wave form (LDS-DMA halo)
+//   7 = 512-thread workgroups                     8 = 16-row x 1-cout-group wave tiles (3x3)
+template <int KH, int KW>
+static bool launch_h2_variant(hipStream_t s, const ConvX6Args &a, int grid)
+{
+    if constexpr (KH > 1) {
+        if (a.Cout != 64) return false;
+        const int v = g_conv_variant;
+        if (!a.x_sc && !((a.Cin >> 4) & 1) && a.zeros && v == 6) {
+            { static bool once = false; if (!once) { once = true; int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_h2_ld_kernel<KH, KW>, 320, 0);
+              fprintf(stderr, "conv_h2_ld_kernel<%d,%d>: occupancy API says %d workgroups of 320 threads per CU\n", KH, KW, nb); } }
+            hipLaunchKernelGGL((conv_h2_ld_kernel<KH, KW>), dim3(grid), dim3(320), 0, s, a);
+            return true;
+        }
+        if (a.x_sc && a.Csc == 32 && v == 1) { hipLaunchKernelGGL((conv_h2_kernel<KH, KW, 4, 2, 0, true>), dim3(grid), dim3(256), 0, s, a); return true; }
+        if (v == 3) { PMP_H2_LAUNCH(4); return true; }     // general shortcut pass / two-workgroup form
+        if (a.x_sc) return false;
+        if (KH == 5 && v >= 10) {   // timing-only ablation builds, 5x5
+            switch (v - 10) {
+            case 1: hipLaunchKernelGGL((conv_h2_kernel<5, 5, 4, false, 1>), dim3(grid), dim3(256), 0, s, a); return true;
+            case 2: hipLaunchKernelGGL((conv_h2_kernel<5, 5, 4, false, 2>), dim3(grid), dim3(256), 0, s, a); return true;
+            case 4: hipLaunchKernelGGL((conv_h2_kernel<5, 5, 4, false, 4>), dim3(grid), dim3(256), 0, s, a); return true;
+            case 8: hipLaunchKernelGGL((conv_h2_kernel<5, 5, 4, false, 8>), dim3(grid), dim3(256), 0, s, a); return true;
+            case 9: hipLaunchKernelGGL((conv_h2_kernel<5, 5, 4, false, 9>), dim3(grid), dim3(256), 0, s, a); return true;
+            case 15: hipLaunchKernelGGL((conv_h2_kernel<5, 5, 4, false, 15>), dim3(grid), dim3(256), 0, s, a); return true;
+            case 32: hipLaunchKernelGGL((conv_h2_kernel<5, 5, 4, false, 32>), dim3(grid), dim3(256), 0, s, a); return true;
+            default: PMP_H2_LAUNCH(4); return true;
+            }
+        }
+        if (KH == 3 && v >= 10) {   // timing-only ablation builds, 3x3
+            switch (v - 10) {
+            case 1: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 1>), dim3(grid), dim3(256), 0, s, a); return true;
+            case 2: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 2>), dim3(grid), dim3(256), 0, s, a); return true;
+            case 4: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 4>), dim3(grid), dim3(256), 0, s, a); return true;
+            case 8: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 8>), dim3(grid), dim3(256), 0, s, a); return true;
+            case 9: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 9>), dim3(grid), dim3(256), 0, s, a); return true;
+            case 15: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 15>), dim3(grid), dim3(256), 0, s, a); return true;
+            case 16: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 16>), dim3(grid), dim3(256), 0, s, a); return true;
+            case 32: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 32>), dim3(grid), dim3(256), 0, s, a); return true;
+            case 64: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 64>), dim3(grid), dim3(256), 0, s, a); return true;
+            case 128: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 128>), dim3(grid), dim3(256), 0, s, a); return true;
+            case 256: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 256>), dim3(grid), dim3(256), 0, s, a); return true;
+            case 1152: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 128, true>), dim3(grid), dim3(256), 0, s, a); return true;   // stamps of the default (three-workgroup) form
+            case 129: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 129>), dim3(grid), dim3(256), 0, s, a); return true;
+            case 130: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 130>), dim3(grid), dim3(256), 0, s, a); return true;
+            case 131: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 131>), dim3(grid), dim3(256), 0, s, a); return true;
+            case 135: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 135>), dim3(grid), dim3(256), 0, s, a); return true;
+            default: PMP_H2_LAUNCH(4); return true;
+            }
+        }
+        if (KH == 3 && v == 8) { hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 0, true, 2>), dim3(grid), dim3(256), 0, s, a); return true; }
+        if (KH == 3 && v == 7) { hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 0, true, 1>), dim3(grid), dim3(512), 0, s, a); return true; }
+        if (!((a.Cin >> 4) & 1) && !(grid & 7) && v == 4) {      // persistent, 2 workgroups per CU, 64 per XCD: 2 % slower
+            hipLaunchKernelGGL((conv_h2_persist_kernel<KH, KW, 4>), dim3(8 * min(64, grid >> 3)), dim3(256), 0, s, a);
+            return true;
+        }
+        if (KH == 3 && !((a.Cin >> 4) & 1) && !(grid & 7) && v == 5) {   // persistent three-workgroup form: spills, 17 % slower
+            hipLaunchKernelGGL((conv_h2_persist_kernel<3, 3, 4, 0, true>), dim3(8 * min(96, grid >> 3)), dim3(256), 0, s, a);
+            return true;
+        }
+    }
+    return false;
+}
+#endif   // PMP_ABLATION
+
 template <int KH, int KW>
 static hipError_t launch_h2(hipStream_t s, const ConvX6Args &a)
 {
     const int grid = a.N * (a.H >> 4) * (a.W >> 4);
-    if constexpr (KH > 1) {   // loader-wave form (5 waves per workgroup): opt-in for A/B
-        if (a.Cout == 64 && !a.x_sc && !((a.Cin >> 4) & 1) && a.zeros && g_conv_variant == 6) {
 #ifdef PMP_ABLATION
-            { static bool once = false; if (!once) { once = true; int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_h2_ld_kernel<KH, KW>, 320, 0);
-              fprintf(stderr, "conv_h2_ld_kernel<%d,%d>: occupancy API says %d workgroups of 320 threads per CU\n", KH, KW, nb); } }
+    if (launch_h2_variant<KH, KW>(s, a, grid)) return hipGetLastError();
 #endif
-            hipLaunchKernelGGL((conv_h2_ld_kernel<KH, KW>), dim3(grid), dim3(320), 0, s, a);
-            return hipGetLastError();
-        }
-    }
-    // the 1x1 shortcut source is a separate instantiation: its extra live state would spill in the common kernel
-#define PMP_H2_LAUNCH(NT)                                                                                          \
-    if (a.x_sc) hipLaunchKernelGGL((conv_h2_kernel<KH, KW, NT, true>), dim3(grid), dim3(256), 0, s, a);           \
-    else hipLaunchKernelGGL((conv_h2_kernel<KH, KW, NT, false>), dim3(grid), dim3(256), 0, s, a)
     switch (a.Cout >> 4) {
     case 1: PMP_H2_LAUNCH(1); break;
     case 2: PMP_H2_LAUNCH(2); break;
     case 4:
-        if (KH > 1 && a.x_sc && a.Csc == 32 && g_conv_variant == 1) {   // A/B: the 32-channel shortcut form at three workgroups per CU
-            hipLaunchKernelGGL((conv_h2_kernel<KH, KW, 4, 2, 0, true>), dim3(grid), dim3(256), 0, s, a);
-        } else if (KH > 1 && a.x_sc && a.Csc == 32 && g_conv_variant != 3) {   // variant 3: the general shortcut pass, for A/B timing
-            // two workgroups per CU: in the 168-VGPR form these kernels measure the same (5x5 class 5.94 vs 5.95 ms per 1024 blocks)
-            hipLaunchKernelGGL((conv_h2_kernel<KH, KW, 4, 2>), dim3(grid), dim3(256), 0, s, a);
-#ifdef PMP_ABLATION   // timing-only builds (wrong results): only in libpmp_hip_abl.so, never in the product library
-        } else if (KH == 5 && !a.x_sc && g_conv_variant >= 10) {   // timing-only ablation builds, 5x5
-            switch (g_conv_variant - 10) {
-            case 1: hipLaunchKernelGGL((conv_h2_kernel<5, 5, 4, false, 1>), dim3(grid), dim3(256), 0, s, a); break;
-            case 2: hipLaunchKernelGGL((conv_h2_kernel<5, 5, 4, false, 2>), dim3(grid), dim3(256), 0, s, a); break;
-            case 4: hipLaunchKernelGGL((conv_h2_kernel<5, 5, 4, false, 4>), dim3(grid), dim3(256), 0, s, a); break;
-            case 8: hipLaunchKernelGGL((conv_h2_kernel<5, 5, 4, false, 8>), dim3(grid), dim3(256), 0, s, a); break;
-            case 9: hipLaunchKernelGGL((conv_h2_kernel<5, 5, 4, false, 9>), dim3(grid), dim3(256), 0, s, a); break;
-            case 15: hipLaunchKernelGGL((conv_h2_kernel<5, 5, 4, false, 15>), dim3(grid), dim3(256), 0, s, a); break;
-            case 32: hipLaunchKernelGGL((conv_h2_kernel<5, 5, 4, false, 32>), dim3(grid), dim3(256), 0, s, a); break;
-            default: PMP_H2_LAUNCH(4); break;
+        if constexpr (KH > 1) {
+            if (a.x_sc && a.Csc == 32) {
+                // RB(32,64,k): the whole 32-channel shortcut tile goes to LDS at once (h2_shortcut32); two workgroups per CU - in the
+                // 168-VGPR form these kernels measure the same (5x5 class 5.94 vs 5.95 ms per 1024 blocks)
+                hipLaunchKernelGGL((conv_h2_kernel<KH, KW, 4, 2>), dim3(grid), dim3(256), 0, s, a);
+                break;
             }
-        } else if (KH == 3 && !a.x_sc && g_conv_variant >= 10) {   // timing-only ablation builds
-            switch (g_conv_variant - 10) {
-            case 1: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 1>), dim3(grid), dim3(256), 0, s, a); break;
-            case 2: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 2>), dim3(grid), dim3(256), 0, s, a); break;
-            case 4: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 4>), dim3(grid), dim3(256), 0, s, a); break;
-            case 8: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 8>), dim3(grid), dim3(256), 0, s, a); break;
-            case 9: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 9>), dim3(grid), dim3(256), 0, s, a); break;
-            case 15: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 15>), dim3(grid), dim3(256), 0, s, a); break;
-            case 16: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 16>), dim3(grid), dim3(256), 0, s, a); break;
-            case 32: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 32>), dim3(grid), dim3(256), 0, s, a); break;
-            case 64: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 64>), dim3(grid), dim3(256), 0, s, a); break;
-            case 128: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 128>), dim3(grid), dim3(256), 0, s, a); break;
-            case 256: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 256>), dim3(grid), dim3(256), 0, s, a); break;
-            case 1152: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 128, true>), dim3(grid), dim3(256), 0, s, a); break;   // stamps of the default (three-workgroup) form
-            case 129: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 129>), dim3(grid), dim3(256), 0, s, a); break;
-            case 130: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 130>), dim3(grid), dim3(256), 0, s, a); break;
-            case 131: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 131>), dim3(grid), dim3(256), 0, s, a); break;
-            case 135: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 135>), dim3(grid), dim3(256), 0, s, a); break;
-            default: PMP_H2_LAUNCH(4); break;
+            if (!a.x_sc) {
+                // the Cout = 64 layers without a shortcut source: the 168-VGPR form, three workgroups per CU (3x3: -5.6 %, 5x5: -1.9 %
+                // against the two-workgroup form; the shortcut instantiations would spill 70 registers in this form)
+                hipLaunchKernelGGL((conv_h2_kernel<KH, KW, 4, false, 0, true>), dim3(grid), dim3(256), 0, s, a);
+                break;
             }
-#endif
-        } else if (KH == 3 && !a.x_sc && g_conv_variant == 8) {   // A/B: 4 waves x (16 rows, 1 cout group), three workgroups per CU
-            hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 0, true, 2>), dim3(grid), dim3(256), 0, s, a);
-        } else if (KH == 3 && !a.x_sc && g_conv_variant == 7) {   // 512-thread workgroups (8 waves = 2 row halves x 4 cout groups), two per CU
-            hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 0, true, 1>), dim3(grid), dim3(512), 0, s, a);
-        } else if (KH > 1 && !a.x_sc && g_conv_variant != 3 && g_conv_variant != 4 && g_conv_variant != 5) {
-            // default for the Cout = 64 layers without a shortcut source: the 168-VGPR form, three workgroups per CU
-            // (3x3: -5.6 %, 5x5: -1.9 % against the two-workgroup form, which PMP_CONV_VARIANT=3 selects for A/B timing; the
-            // shortcut instantiations would spill 70 registers in this form and stay as they are)
-            hipLaunchKernelGGL((conv_h2_kernel<KH, KW, 4, false, 0, true>), dim3(grid), dim3(256), 0, s, a);
-        } else if (KH > 1 && !a.x_sc && !((a.Cin >> 4) & 1) && !(grid & 7) && g_conv_variant == 4) {
-            // persistent form (opt-in, PMP_CONV_VARIANT=4): 2 workgroups per CU, 64 per XCD.  Measured 2 % SLOWER than one
-            // workgroup per tile in its two-workgroup form: kept as a tested A/B variant, not the default.
-            hipLaunchKernelGGL((conv_h2_persist_kernel<KH, KW, 4>), dim3(8 * min(64, grid >> 3)), dim3(256), 0, s, a);
-        } else if (KH == 3 && !a.x_sc && !((a.Cin >> 4) & 1) && !(grid & 7) && g_conv_variant == 5) {
-            // persistent three-workgroup form (opt-in, PMP_CONV_VARIANT=5): 96 workgroups per XCD.  The tile loop costs about 50
-            // more VGPRs than 168 leave (216 B of scratch, a third of it inside the K-loop): 17 % slower than the default.
-            hipLaunchKernelGGL((conv_h2_persist_kernel<3, 3, 4, 0, true>), dim3(8 * min(96, grid >> 3)), dim3(256), 0, s, a);
-        } else {
-            PMP_H2_LAUNCH(4);
         }
+        PMP_H2_LAUNCH(4);
         break;
     default: return hipErrorInvalidValue;
     }
-#undef PMP_H2_LAUNCH
     return hipGetLastError();
 }
+#undef PMP_H2_LAUNCH
 
 hipError_t launch_conv_h2(hipStream_t s, const ConvX6Args &a_in)
 {
@@ -834,7 +858,9 @@ hipError_t launch_conv_h2(hipStream_t s, const ConvX6Args &a_in)
         return hipErrorInvalidValue;
     if (a.pool && a.gate) return hipErrorInvalidValue;
     if (!(a.out_scale > 0.f)) return hipErrorInvalidValue;
+#ifdef PMP_ABLATION
     if ((g_conv_variant == 9 || g_conv_variant >= 90) && conv_h2_t32_applicable(a)) return launch_conv_h2_t32(s, a);   // 32x16 tiles, LDS-DMA (A/B: opt-in)
+#endif
     if (a.KH == 3 && a.KW == 3) return launch_h2<3, 3>(s, a);
     if (a.KH == 5 && a.KW == 5) return launch_h2<5, 5>(s, a);
     if (a.KH == 1 && a.KW == 1) return launch_h2<1, 1>(s, a);

@@ -303,7 +303,9 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvMfmaArgs a)
     }
 }
 
-int g_conv_variant = 2;  // 0: un-pipelined; 1: pipelined, 3 waves/SIMD; 2: fully pipelined, 2 waves/SIMD (A/B measurements)
+#ifdef PMP_ABLATION
+int g_conv_variant = 2;  // measurement library only: 0: un-pipelined; 1: pipelined, 3 waves/SIMD; 2: the shipped form (A/B measurements)
+#endif
 
 template <int KH, int KW, int PIPE, int OCC>
 static hipError_t launch_k(hipStream_t s, const ConvMfmaArgs &a)
@@ -323,11 +325,16 @@ hipError_t launch_conv_mfma(hipStream_t s, const ConvMfmaArgs &a)
     if ((a.H & 15) || (a.W & 15) || (a.Cin & 15) || (a.Cout & 15) || (a.x_sc && (a.Csc & 15)) || a.N <= 0)
         return hipErrorInvalidValue;
     if (a.pool && a.gate) return hipErrorInvalidValue;
+#ifdef PMP_ABLATION
     const int v = g_conv_variant > 2 ? 2 : g_conv_variant;
-    if (a.KH == 3 && a.KW == 3)
-        return v == 0 ? launch_k<3, 3, 0, 1>(s, a) : (v == 1 ? launch_k<3, 3, 1, 3>(s, a) : launch_k<3, 3, 2, 2>(s, a));
-    if (a.KH == 5 && a.KW == 5)
-        return v == 0 ? launch_k<5, 5, 0, 1>(s, a) : (v == 1 ? launch_k<5, 5, 1, 3>(s, a) : launch_k<5, 5, 2, 2>(s, a));
+    if (v < 2) {
+        if (a.KH == 3 && a.KW == 3) return v == 0 ? launch_k<3, 3, 0, 1>(s, a) : launch_k<3, 3, 1, 3>(s, a);
+        if (a.KH == 5 && a.KW == 5) return v == 0 ? launch_k<5, 5, 0, 1>(s, a) : launch_k<5, 5, 1, 3>(s, a);
+    }
+#endif
+    // shipped form: fully software-pipelined, two waves per SIMD
+    if (a.KH == 3 && a.KW == 3) return launch_k<3, 3, 2, 2>(s, a);
+    if (a.KH == 5 && a.KW == 5) return launch_k<5, 5, 2, 2>(s, a);
     if (a.KH == 1 && a.KW == 1) return launch_k<1, 1, 0, 1>(s, a);
     return hipErrorInvalidValue;
 }

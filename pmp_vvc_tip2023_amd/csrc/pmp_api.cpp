@@ -108,7 +108,10 @@ static int infer_passes(pmp_ctx *c, bool luma, const NetWeights &wq, const NetWe
     return PMP_OK;
 }
 
-// Reads and clears the device-side saturation word (synchronises the stream).
+// ---- f16x3 range guard (include/pmp.h) ----------------------------------------------------------------------------------
+constexpr int PMP_SAT_SLOTS = 64;
+
+// Reads and clears the device-side saturation word (synchronises the stream): PMP_SAT_IGNORE contexts, whose calls take no snapshots.
 static int sat_fetch(pmp_ctx *c, unsigned *out)
 {
     unsigned h = 0;
@@ -120,6 +123,60 @@ static int sat_fetch(pmp_ctx *c, unsigned *out)
     return PMP_OK;
 }
 
+static void drop_pending(pmp_ctx *c)
+{
+    for (auto &p : c->pending) if (p.ev) c->event_pool.push_back(p.ev);
+    c->pending.clear();
+}
+
+static int count_pending_infer(const pmp_ctx *c)
+{
+    int k = 0;
+    for (const auto &p : c->pending) k += p.infer;
+    return k;
+}
+
+// Looks at the flag snapshots of the calls in flight, oldest first.  wait = false: only those whose event has completed (a later
+// call polling, no host stall); wait = true: all of them (pmp_synchronize, pmp_get_saturation, host-pointer calls).  The first
+// fired flag drains the stream once - from then on every later snapshot is final - and from there on, in order: a fired inference
+// call runs again on bf16x6, a post-processing call behind a re-run inference call is replayed.  Everything re-enqueued is ordered
+// on the stream; the caller synchronises if it needs the results on the host.
+static int resolve_pending(pmp_ctx *c, bool wait)
+{
+    bool dirty = false;
+    while (!c->pending.empty()) {
+        PendingCall &p = c->pending.front();
+        int rc = PMP_OK;
+        if (p.infer) {
+            if (!dirty) {
+                hipError_t e = wait ? hipEventSynchronize(p.ev) : hipEventQuery(p.ev);
+                if (e == hipErrorNotReady) break;
+                if (e != hipSuccess) { drop_pending(c); return hip_fail(c, e, "saturation flag event"); }
+            }
+            if (*p.slot) {
+                c->sat_seen = 1;
+                if (c->sat_policy == PMP_SAT_ERROR) {
+                    drop_pending(c);
+                    return set_err(c, PMP_E_RANGE, "pmp_infer: an activation exceeded the fp16 range of the f16x3 datapath (use bf16x6 or fp32)");
+                }
+                if (!dirty) {
+                    hipError_t e = hipStreamSynchronize(c->stream);
+                    if (e != hipSuccess) { drop_pending(c); return hip_fail(c, e, "hipStreamSynchronize"); }
+                    dirty = true;
+                }
+                c->sat_reruns += 1;
+                rc = p.rerun();
+            }
+        } else if (dirty) {
+            rc = p.rerun();
+        }
+        if (p.ev) c->event_pool.push_back(p.ev);
+        c->pending.pop_front();
+        if (rc != PMP_OK) { drop_pending(c); return rc; }
+    }
+    return PMP_OK;
+}
+
 static int infer_device_impl(pmp_ctx *c, int comp, int qp, const uint8_t *by, const uint8_t *bu, const uint8_t *bv,
                              int64_t n, float *qt, float *bt, float *dire)
 {
@@ -127,23 +184,41 @@ static int infer_device_impl(pmp_ctx *c, int comp, int qp, const uint8_t *by, co
     if (n < 0 || !by || !qt || !bt || !dire || (comp == PMP_CHROMA && (!bu || !bv)))
         return set_err(c, PMP_E_INVALID, "pmp_infer: null buffer or negative count");
     const bool luma = comp == PMP_LUMA;
-    const NetWeights *wq = find_net(c, luma ? PMP_NET_LUMA_Q : PMP_NET_CHROMA_Q, qp);
-    const NetWeights *wb = find_net(c, luma ? PMP_NET_LUMA_MSBD : PMP_NET_CHROMA_MSBD, qp);
+    const int id_q = luma ? PMP_NET_LUMA_Q : PMP_NET_CHROMA_Q, id_b = luma ? PMP_NET_LUMA_MSBD : PMP_NET_CHROMA_MSBD;
+    const NetWeights *wq = find_net(c, id_q, qp);
+    const NetWeights *wb = find_net(c, id_b, qp);
     if (!wq || !wb) return set_err(c, PMP_E_NOWEIGHTS, "pmp_infer: weights for this (comp, qp) are not loaded");
-    int rc = infer_passes(c, luma, *wq, *wb, by, bu, bv, n, qt, bt, dire);
-    if (rc != PMP_OK || c->precision != PMP_PRECISION_F16X3 || c->sat_policy == PMP_SAT_IGNORE || n == 0) return rc;
-    // f16x3 range guard: did any stored activation leave the fp16 range during this call?
-    unsigned fired = 0;
-    if ((rc = sat_fetch(c, &fired)) != PMP_OK || !fired) return rc;
-    c->sat_seen = 1;
-    if (c->sat_policy == PMP_SAT_ERROR)
-        return set_err(c, PMP_E_RANGE, "pmp_infer: an activation exceeded the fp16 range of the f16x3 datapath (use bf16x6 or fp32)");
-    c->sat_reruns += 1;
-    c->precision = PMP_PRECISION_BF16X6;            // three bf16 terms: fp32's exponent range, fp32-equivalent products
+    int rc = resolve_pending(c, false);          // earlier calls whose snapshot has landed by now: no wait
+    if (rc != PMP_OK) return rc;
     rc = infer_passes(c, luma, *wq, *wb, by, bu, bv, n, qt, bt, dire);
-    c->precision = PMP_PRECISION_F16X3;
-    if (rc == PMP_OK) rc = sync(c);
-    return rc;
+    if (rc != PMP_OK || c->precision != PMP_PRECISION_F16X3 || c->sat_policy == PMP_SAT_IGNORE || n == 0) return rc;
+    // f16x3 range guard: snapshot the flag behind this call's passes and reset it for the next call - all stream-ordered, the host
+    // does not wait.  Whoever looks at the snapshot later (resolve_pending) re-runs the call on bf16x6 if it fired.
+    if (count_pending_infer(c) >= PMP_SAT_SLOTS && (rc = resolve_pending(c, true)) != PMP_OK) return rc;
+    unsigned *slot = c->h_sat + (c->sat_seq++ % PMP_SAT_SLOTS);
+    *slot = 0;
+    hipError_t e = hipMemcpyAsync(slot, c->d_sat, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_sat, 0, sizeof(unsigned), c->stream);
+    hipEvent_t ev = get_event(c);
+    if (e == hipSuccess) e = hipEventRecord(ev, c->stream);
+    if (e != hipSuccess) { c->event_pool.push_back(ev); return hip_fail(c, e, "saturation flag snapshot"); }
+    c->pending.push_back(PendingCall{true, ev, slot, [=]() {
+        const NetWeights *rq = find_net(c, id_q, qp), *rb = find_net(c, id_b, qp);   // loading weights resolves first: still the same nets
+        if (!rq || !rb) return set_err(c, PMP_E_NOWEIGHTS, "pmp_infer: weights vanished before the range-guard re-run");
+        c->precision = PMP_PRECISION_BF16X6;        // three bf16 terms: fp32's exponent range, fp32-equivalent products
+        const int r2 = infer_passes(c, luma, *rq, *rb, by, bu, bv, n, qt, bt, dire);
+        c->precision = PMP_PRECISION_F16X3;
+        return r2;
+    }});
+    return PMP_OK;
+}
+
+static int post_launch(pmp_ctx *c, int comp, const float *qt, const float *bt, const float *dire, int64_t n, uint8_t *hor, uint8_t *ver,
+                       uint8_t *qt_u8, int8_t *dire_i8, int record_stride)
+{
+    KScope ks(c, K_POST, 0.0);
+    hipError_t e = launch_postprocess(c->stream, qt, bt, dire, n, comp == PMP_LUMA ? 1 : 2, hor, ver, qt_u8, dire_i8, record_stride);
+    return e == hipSuccess ? PMP_OK : hip_fail(c, e, "postprocess");
 }
 
 static int post_device_impl(pmp_ctx *c, int comp, const float *qt, const float *bt, const float *dire, int64_t n,
@@ -152,15 +227,24 @@ static int post_device_impl(pmp_ctx *c, int comp, const float *qt, const float *
     if (comp != PMP_LUMA && comp != PMP_CHROMA) return set_err(c, PMP_E_INVALID, "pmp_postprocess: bad comp");
     if (n < 0 || !qt || !bt || !dire || !hor || !ver || !qt_u8 || !dire_i8)
         return set_err(c, PMP_E_INVALID, "pmp_postprocess: null buffer or negative count");
-    KScope ks(c, K_POST, 0.0);
-    hipError_t e = launch_postprocess(c->stream, qt, bt, dire, n, comp == PMP_LUMA ? 1 : 2, hor, ver, qt_u8, dire_i8, record_stride);
-    return e == hipSuccess ? PMP_OK : hip_fail(c, e, "postprocess");
+    const int rc = post_launch(c, comp, qt, bt, dire, n, hor, ver, qt_u8, dire_i8, record_stride);
+    // its logits may come from an inference call whose range flag has not been looked at yet: remember the call for the replay
+    if (rc == PMP_OK && !c->pending.empty())
+        c->pending.push_back(PendingCall{false, nullptr, nullptr, [=]() { return post_launch(c, comp, qt, bt, dire, n, hor, ver, qt_u8, dire_i8, record_stride); }});
+    return rc;
 }
 
 static int sync(pmp_ctx *c)
 {
     hipError_t e = hipStreamSynchronize(c->stream);
     return e == hipSuccess ? PMP_OK : hip_fail(c, e, "hipStreamSynchronize");
+}
+
+// Everything this context has been asked to do is done and final: range flags looked at, re-runs finished.
+static int settle(pmp_ctx *c)
+{
+    int rc = resolve_pending(c, true);
+    return rc != PMP_OK ? rc : sync(c);
 }
 
 static int h2d(pmp_ctx *c, DevBuf &b, const void *src, size_t bytes)
@@ -226,6 +310,12 @@ int pmp_create(int device_id, pmp_ctx **out)
         delete c;
         return hip_fail(nullptr, e, "hipMalloc(saturation flag)");
     }
+    if ((e = hipHostMalloc((void **)&c->h_sat, PMP_SAT_SLOTS * sizeof(unsigned), hipHostMallocDefault)) != hipSuccess) {
+        hipFree(c->d_sat);
+        hipStreamDestroy(c->own_stream);
+        delete c;
+        return hip_fail(nullptr, e, "hipHostMalloc(saturation snapshots)");
+    }
     *out = c;
     return PMP_OK;
 }
@@ -235,6 +325,7 @@ int pmp_destroy(pmp_ctx *c)
     if (!c) return PMP_OK;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    drop_pending(c);
     ktime_drain(c);
     for (auto &kv : c->nets) free_net_weights(kv.second);
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
@@ -242,6 +333,7 @@ int pmp_destroy(pmp_ctx *c)
                       &c->d_out[0], &c->d_out[1], &c->d_out[2], &c->d_out[3], &c->d_frames[0], &c->d_frames[1], &c->d_frames[2]};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     if (c->d_sat) hipFree(c->d_sat);
+    if (c->h_sat) hipHostFree(c->h_sat);
     hipStreamDestroy(c->own_stream);
     delete c;
     return PMP_OK;
@@ -250,11 +342,12 @@ int pmp_destroy(pmp_ctx *c)
 int pmp_set_stream(pmp_ctx *c, void *hip_stream)
 {
     CHECK_CTX(c);
+    if (!c->pending.empty()) { const int rc = settle(c); if (rc != PMP_OK) return rc; }   // calls in flight belong to the old stream
     c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
     return PMP_OK;
 }
 
-int pmp_synchronize(pmp_ctx *c) { CHECK_CTX(c); return sync(c); }
+int pmp_synchronize(pmp_ctx *c) { CHECK_CTX(c); return settle(c); }
 
 int pmp_set_chunk(pmp_ctx *c, int blocks)
 {
@@ -271,7 +364,7 @@ int pmp_set_precision(pmp_ctx *c, int mode)
     CHECK_CTX(c);
     if (mode != PMP_PRECISION_F32 && mode != PMP_PRECISION_BF16X6 && mode != PMP_PRECISION_F16X3)
         return set_err(c, PMP_E_INVALID, "pmp_set_precision: 0 (fp32), 1 (bf16x6) or 2 (f16x3)");
-    int rc = sync(c);
+    int rc = settle(c);
     if (rc != PMP_OK) return rc;
     c->precision = mode;
     return PMP_OK;
@@ -284,6 +377,7 @@ int pmp_set_saturation_policy(pmp_ctx *c, int policy)
     CHECK_CTX(c);
     if (policy != PMP_SAT_RERUN && policy != PMP_SAT_ERROR && policy != PMP_SAT_IGNORE)
         return set_err(c, PMP_E_INVALID, "pmp_set_saturation_policy: PMP_SAT_RERUN, PMP_SAT_ERROR or PMP_SAT_IGNORE");
+    if (!c->pending.empty()) { const int rc = settle(c); if (rc != PMP_OK) return rc; }   // calls in flight keep the policy they were made under
     c->sat_policy = policy;
     return PMP_OK;
 }
@@ -291,9 +385,10 @@ int pmp_set_saturation_policy(pmp_ctx *c, int policy)
 int pmp_get_saturation(pmp_ctx *c)
 {
     CHECK_CTX(c);
-    unsigned fired = 0;   // under PMP_SAT_IGNORE nothing has read the device word yet
-    int rc = sat_fetch(c, &fired);
+    int rc = settle(c);          // flags of the calls in flight (re-runs included)
     if (rc != PMP_OK) return rc;
+    unsigned fired = 0;          // under PMP_SAT_IGNORE no call takes a snapshot: read the device word itself
+    if ((rc = sat_fetch(c, &fired)) != PMP_OK) return rc;
     if (fired) c->sat_seen = 1;
     return c->sat_seen;
 }
@@ -304,7 +399,8 @@ int pmp_clear_saturation(pmp_ctx *c)
 {
     CHECK_CTX(c);
     unsigned fired = 0;
-    int rc = sat_fetch(c, &fired);
+    int rc = settle(c);
+    if (rc == PMP_OK) rc = sat_fetch(c, &fired);
     c->sat_seen = 0;
     c->sat_reruns = 0;
     return rc;
@@ -313,7 +409,7 @@ int pmp_clear_saturation(pmp_ctx *c)
 int pmp_load_weights(pmp_ctx *c, int net_id, int qp, const float *blob, const pmp_tensor_desc *descs, int ndesc)
 {
     CHECK_CTX(c);
-    int rc = sync(c);
+    int rc = settle(c);     // a range-guard re-run of a call in flight must still find the weights it ran with
     if (rc != PMP_OK) return rc;
     return load_net_weights(c, net_id, qp, blob, descs, ndesc);
 }
@@ -334,7 +430,7 @@ int pmp_load_weights_file(pmp_ctx *c, int net_id, int qp, const char *path)
         for (int j = 0; j < 4; ++j) descs[i].shape[j] = wf.tensors[i].shape[j];
         descs[i].offset = wf.tensors[i].offset;
     }
-    if ((rc = sync(c)) != PMP_OK) return rc;
+    if ((rc = settle(c)) != PMP_OK) return rc;
     return load_net_weights(c, net_id, qp, wf.payload.data(), descs.data(), (int)descs.size());
 }
 
@@ -428,6 +524,7 @@ int pmp_infer(pmp_ctx *c, int comp, int qp, const uint8_t *by, const uint8_t *bu
     if ((rc = infer_device_impl(c, comp, qp, (const uint8_t *)c->d_in[0].p, (const uint8_t *)c->d_in[1].p,
                                 (const uint8_t *)c->d_in[2].p, n, dq, db, dd)))
         return rc;
+    if ((rc = resolve_pending(c, true))) return rc;      // range guard: a re-run is enqueued before the copies below
     if ((rc = d2h(c, qt, dq, (size_t)n * 64 * 4)) || (rc = d2h(c, bt, db, (size_t)n * 768 * 4)) ||
         (rc = d2h(c, dire, dd, (size_t)n * 768 * 4)))
         return rc;
@@ -446,6 +543,7 @@ static int alloc_out(pmp_ctx *c, int64_t n)
 static int fetch_out(pmp_ctx *c, int64_t n, uint8_t *hor, uint8_t *ver, uint8_t *qt_u8, int8_t *dire_i8)
 {
     int rc;
+    if ((rc = resolve_pending(c, true))) return rc;      // range guard: re-run and replay are enqueued before the copies below
     if ((rc = d2h(c, hor, c->d_out[0].p, (size_t)n * 256)) || (rc = d2h(c, ver, c->d_out[1].p, (size_t)n * 256)) ||
         (rc = d2h(c, qt_u8, c->d_out[2].p, (size_t)n * 64)) || (rc = d2h(c, dire_i8, c->d_out[3].p, (size_t)n * 768)))
         return rc;
@@ -489,6 +587,7 @@ int pmp_infer_postprocess(pmp_ctx *c, int comp, int qp, const uint8_t *by, const
     if ((rc = post_device_impl(c, comp, dq, db, dd, n, (uint8_t *)c->d_out[0].p, (uint8_t *)c->d_out[1].p,
                                (uint8_t *)c->d_out[2].p, (int8_t *)c->d_out[3].p)))
         return rc;
+    if ((rc = resolve_pending(c, true))) return rc;
     if ((rc = d2h(c, qt, dq, (size_t)n * 64 * 4)) || (rc = d2h(c, bt, db, (size_t)n * 768 * 4)) ||
         (rc = d2h(c, dire, dd, (size_t)n * 768 * 4)))
         return rc;
@@ -533,13 +632,14 @@ int pmp_debug_set_conv_variant(int variant)
 {
 #ifdef PMP_ABLATION
     if (variant < 0 || variant > 4095) return set_err(nullptr, PMP_E_INVALID, "pmp_debug_set_conv_variant: 0..9, or 10 + bits for the timing-only builds");
-#else
-    // every variant the product library accepts computes bit-identical results; the timing-only builds (>= 10, wrong
-    // results) exist only in libpmp_hip_abl.so (make abl)
-    if (variant < 0 || variant > 9) return set_err(nullptr, PMP_E_INVALID, "pmp_debug_set_conv_variant: 0..9 (timing-only builds are not part of this library)");
-#endif
     g_conv_variant = variant;
     return PMP_OK;
+#else
+    // the product library ships ONE form of every kernel (number 2): there is no process-wide selector in it.  The A/B forms
+    // (bit-identical, measured slower or equal) and the timing-only builds live in libpmp_hip_abl.so (make abl)
+    if (variant != 2) return set_err(nullptr, PMP_E_INVALID, "pmp_debug_set_conv_variant: this library ships only the default form (2); the A/B and timing-only builds are in libpmp_hip_abl.so (make abl)");
+    return PMP_OK;
+#endif
 }
 
 int pmp_debug_conv_bench(pmp_ctx *c, int n, int h, int w, int cin, int cout, int k, int iters, double *ms_f32, double *ms_x6,

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <deque>
+#include <functional>
 #include <map>
 #include <string>
 #include <utility>
@@ -85,6 +87,17 @@ struct Arena {
 
 struct KTimeRec { hipEvent_t a, b; double flops; };
 
+// f16x3 range guard, deferred (include/pmp.h): every inference call snapshots the device flag into a pinned host word behind its
+// passes and records an event; the word is read when the event has completed - at a later call (polled), at pmp_synchronize /
+// pmp_get_saturation or at the end of a host-pointer call (waited for).  A call whose flag fired is run again on bf16x6 and every
+// post-processing call enqueued after it is replayed, in order, on the same buffers.
+struct PendingCall {
+    bool infer;                       // inference (has a flag snapshot) or a post-processing call recorded for replay
+    hipEvent_t ev;                    // infer: completes when the snapshot has landed
+    unsigned *slot;                   // infer: pinned host word
+    std::function<int()> rerun;       // infer: the same call on bf16x6;  post: the same call again
+};
+
 }  // namespace pmp
 
 struct pmp_ctx {
@@ -96,6 +109,9 @@ struct pmp_ctx {
     // f16x3 range guard (include/pmp.h, pmp_set_saturation_policy): device word raised by every kernel that clamps a stored activation.
     // A 256-byte block: word 0 is the flag, bytes 64.. stay zero (the zero line of conv_f16x3_t32.hip's halo DMA)
     unsigned *d_sat = nullptr;
+    unsigned *h_sat = nullptr;             // PMP_SAT_SLOTS pinned host words: flag snapshots of the calls still in flight
+    uint64_t sat_seq = 0;
+    std::deque<pmp::PendingCall> pending;  // calls whose flag has not been looked at yet (+ the post-processing calls after them)
     int sat_policy = PMP_SAT_RERUN;
     int sat_seen = 0;                      // sticky: some inference call since pmp_clear_saturation saturated
     int64_t sat_reruns = 0;                // calls re-run on the bf16x6 datapath

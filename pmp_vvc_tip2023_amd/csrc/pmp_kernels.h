@@ -25,7 +25,9 @@ struct ConvMfmaArgs {
     int relu, pool;
 };
 hipError_t launch_conv_mfma(hipStream_t s, const ConvMfmaArgs &a);
-extern int g_conv_variant;  // see pmp_debug_set_conv_variant
+#ifdef PMP_ABLATION
+extern int g_conv_variant;  // measurement library only (make abl): see pmp_debug_set_conv_variant
+#endif
 
 // ------------------------------------------------------------------------------------------------ conv (bf16 x 6)
 // Same operation on "split-3" activations (three bf16 planes per tensor, conv_bf16x6.hip).  *_stride = elements between
@@ -52,9 +54,11 @@ hipError_t launch_split3_to_f32(hipStream_t s, const unsigned short *x, float *o
 // Same operation on "split-2" activations (two fp16 planes) with three fp16 MFMA products per term (conv_f16x3.hip).
 // Weights packed [K-step][2 splits][Cout/16][64 lanes][8 fp16], pre-multiplied by 1/out_scale.
 hipError_t launch_conv_h2(hipStream_t s, const ConvX6Args &a);
-// conv_f16x3_t32.hip: the 3x3 64->64 trunk convolution on 32x16 tiles (LDS-DMA halo, hand-counted vmcnt)
+#ifdef PMP_ABLATION
+// conv_f16x3_t32.hip (measurement library only): the 3x3 64->64 trunk convolution on 32x16 tiles (LDS-DMA halo, hand-counted vmcnt)
 bool conv_h2_t32_applicable(const ConvX6Args &a);
 hipError_t launch_conv_h2_t32(hipStream_t s, const ConvX6Args &a);
+#endif
 hipError_t launch_f32_to_split2(hipStream_t s, const float *x, unsigned short *out, size_t n, size_t plane_stride, unsigned *sat = nullptr);
 hipError_t launch_split2_to_f32(hipStream_t s, const unsigned short *x, float *out, size_t n, size_t plane_stride);
 
