@@ -133,44 +133,44 @@ def measure_extras(eng, args, dev, n, y, u, v, step):
             eng.load("Luma", qp)
             per_qp[str(qp)] = round(n / 4.0 / timed(lambda: step("Luma", qp), 3), 2)
         eng.load("Chroma", 22)
-        out["extra"] = {"luma_ctu_per_s_by_qp": per_qp, "chroma_qp22_ctu_per_s": round(n / 4.0 / timed(lambda: step("Chroma", 22), 3), 2),
+        chroma_dt = timed(lambda: step("Chroma", 22), 3)
+        out["extra"] = {"luma_ctu_per_s_by_qp": per_qp, "chroma_qp22_ctu_per_s": round(n / 4.0 / chroma_dt, 2),
                         "note": "device-resident step, 3 steps each after 1 warm-up; same blocks; chroma counts the 64x64-luma-area "
                                 "block (34x34 chroma inputs) as the unit, as the luma figure does"}
+
+        def classes(comp):
+            """hipEvent time of every kernel class over 3 steps (events around every launch: a few % slower than the untimed step)."""
+            eng.ktime_enable(0xFFFF)
+            for _ in range(3):
+                step(comp, 22)
+            kt = eng.ktime()
+            eng.ktime_enable(0)
+            return {k: {"launches_per_step": round(ln / 3.0, 2), "ms_per_step": round(ms / 3.0, 4),
+                        "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if ms else None} for k, (ln, ms, fl) in kt.items() if ln}
+        peak = PEAK_TFLOPS[args.precision]
+        cl_luma, cl_chroma = classes("Luma"), classes("Chroma")
+        out["breakdown"] = {"luma": cl_luma, "chroma": cl_chroma,
+                            "note": "per kernel class, %d blocks per step; conv classes carry algorithmic FLOPs (2 per MAC), the others 0" % n}
+        c_net = n / chroma_dt * FLOP_PER_BLOCK["Chroma"] / 1e12
+        dom = max((k for k in cl_chroma if cl_chroma[k]["tflops"]), key=lambda k: cl_chroma[k]["ms_per_step"])
+        out["chroma_roofline"] = {"bound": "mfma", "kernel": dom, "achieved": cl_chroma[dom]["tflops"], "peak": round(peak, 1), "unit": "TFLOP/s",
+                                  "frac": round(cl_chroma[dom]["tflops"] / peak, 4), "net_tflops": round(c_net, 2),
+                                  "net_frac": round(c_net / peak, 4), "blocks_per_s": round(n / chroma_dt, 1),
+                                  "note": "Chroma QT+MTT QP22, 2.300 GFLOP per block (SURVEY 8d); dominant class by time"}
     return out
 
 
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (this parent never touches the GPU - a
-    process that has initialised HIP must not be replaced or forked into ranks) and relay rank 0's stdout."""
-    import socket
-    import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-               PMP_BENCH_CHILD="1")
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
-    procs = []
-    for r in range(n):
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
-                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
-    out0 = b""
-    rc = 0
-    try:
-        out0 = procs[0].communicate()[0]
-        for p in procs:
-            p.wait()
-            rc = rc or p.returncode
-    except BaseException:
-        rc = rc or 1
-        raise
-    finally:
-        for p in procs:                                        # a rank that died leaves the others at a barrier: end them by PID
-            if p.poll() is None:
-                p.kill()
-    sys.stdout.write(out0.decode())
-    sys.stdout.flush()
+    process that has initialised HIP must not be replaced or forked into ranks), watch ALL of them - the first rank that fails
+    ends the job at once with its exit code, the others are killed by PID - and relay rank 0's stdout."""
+    from pmp_vvc_tip2023_amd import parallel            # numpy only: no GPU call
+    rc, out0 = parallel.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], n, env_extra={"PMP_BENCH_CHILD": "1"},
+                                    capture_rank0=True)
+    out0 = out0 or b""
+    if rc == 0:
+        sys.stdout.write(out0.decode())
+        sys.stdout.flush()
     return rc or (0 if out0.strip() else 1)
 
 
@@ -218,14 +218,19 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    preflight = None
     if n_gpus > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("PMP_DIST_BACKEND", "nccl")     # "nccl" = RCCL; "gloo" only to smoke-test the control flow
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        from pmp_vvc_tip2023_amd import parallel
+        os.environ.setdefault("PMP_DIST_BACKEND", "nccl")        # "nccl" = RCCL; "gloo" only to smoke-test the control flow
+        try:
+            parallel.init_process_group(dev)                     # bounded: a rank that never arrives is an error, not a hang
+            # first collective, content verified, BEFORE any timing: a broken RCCL / IPC setup ends here with a message
+            preflight = parallel.preflight(dev)
+        except Exception as e:                                    # noqa: BLE001
+            log("bench.py: rank %d: multi-GPU preflight failed: %s" % (rank, e))
+            raise SystemExit(3)
+        log("rank %d: preflight ok: %d ranks over %s, %.1f ms" % (rank, preflight["ranks"], preflight["backend"], preflight["ms"]))
 
     from pmp_vvc_tip2023_amd import _lib, engine, synth
     if args.lib:
@@ -254,20 +259,33 @@ def main():
     pu = d_u.data_ptr() if args.comp == "Chroma" else None
     pv = d_v.data_ptr() if args.comp == "Chroma" else None
 
-    def step(comp=args.comp, qp=args.qp):
+    gather_events = []          # (start, end) event pairs around the collective, on the stream it is ordered on
+    gather_host_s = [0.0]
+
+    def step(comp=args.comp, qp=args.qp, timed=False):
         chroma = comp == "Chroma"
         eng.infer_postprocess_records_device(comp, qp, d_y.data_ptr(), d_u.data_ptr() if chroma else None,
                                              d_v.data_ptr() if chroma else None, n, res.data_ptr())
         if n_gpus > 1:
             # the path's only exchange: split-flag records of every shard go to rank 0, which owns the file writer
             if dist.get_backend() == "nccl":
+                if timed:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
                 dist.gather(res, list(gathered.split(n)) if rank == 0 else None, dst=0)      # RCCL, device to device over xGMI
+                if timed:
+                    e1.record(stream)
+                    gather_events.append((e0, e1))
             else:
+                eng.synchronize()
+                th = time.perf_counter()
                 rc = res.cpu()
                 dist.gather(rc, [torch.empty_like(rc) for _ in range(world)] if rank == 0 else None, dst=0)
+                gather_host_s[0] += (time.perf_counter() - th) if timed else 0.0
 
     for _ in range(args.warmup):
         step()
+    eng.synchronize()
     torch.cuda.synchronize(dev)
     mask = 1 << [eng.lib.pmp_ktime_name(k).decode() for k in range(eng.lib.pmp_ktime_classes())].index(DOMINANT)
     eng.ktime_enable(mask)
@@ -276,17 +294,33 @@ def main():
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        step(timed=True)
+    eng.synchronize()            # every step's range-guard snapshot looked at (and a saturated step re-run) inside the timed region
+    own_elapsed = time.perf_counter() - t0
     if dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     kt = eng.ktime()
     eng.ktime_enable(0)
+    multi = None
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        cpu_side = dist.get_backend() != "nccl"
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if cpu_side else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # what the collective cost and how even the ranks were: if the N-GPU number disappoints, the line says why
+        g_ms = (sum(a.elapsed_time(b) for a, b in gather_events) if gather_events else gather_host_s[0] * 1e3) / max(args.steps, 1)
+        mine = torch.tensor([own_elapsed / args.steps * 1e3, g_ms], dtype=torch.float64, device="cpu" if cpu_side else dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        multi = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                 "gather_bytes_per_step": n * 1344 * world, "gather_ms": round(float(every[0][1].item()), 4),
+                 "gather_ms_by_rank": [round(float(e[1].item()), 4) for e in every],
+                 "ms_per_step_by_rank": [round(float(e[0].item()), 4) for e in every],
+                 "preflight_ms": round(preflight["ms"], 2) if preflight else None,
+                 "note": "gather_ms: events around the collective on rank 0's stream (it waits for the slowest rank's records, so skew "
+                         "shows up here); ms_per_step_by_rank: each rank's own loop before the closing barrier"}
 
     blocks_per_s = n * n_gpus * args.steps / elapsed
     launches, ms, flops = kt[DOMINANT]
@@ -348,6 +382,9 @@ def main():
             "net_tflops": round(blocks_per_s * FLOP_PER_BLOCK[args.comp] / 1e12, 2),
             "roofline": roof,
         }
+        if multi:
+            out["multi_gpu"] = multi
+            out["rccl_ranks"] = multi["rccl_ranks"]
         out.update(extras)
         if args.cpu_sample > 0 and n_gpus == 1 and args.comp == "Luma":
             out["cpu_baseline"], out["parity"] = cpu_baseline(args.cpu_sample, 1, eng)

@@ -50,18 +50,115 @@ def unpack_records(rec):
             rec[:, 512:576].reshape(n, 8, 8).copy(), rec[:, 576:].copy().view(np.int8).reshape(n, 3, 16, 16))
 
 
-def init_process_group(device=None):
-    """Join the torchrun rendezvous (no-op for world 1).  Returns (rank, world, local_rank)."""
+INIT_TIMEOUT_S = 180      # rendezvous + first collective: a rank that never arrives becomes an error, not a hang
+
+
+def init_process_group(device=None, timeout_s=None):
+    """Join the torchrun rendezvous (no-op for world 1).  Returns (rank, world, local_rank).  The timeout bounds the rendezvous
+    and every later collective (PMP_DIST_TIMEOUT_S overrides): a missing rank ends the job with an error instead of hanging it."""
     rank, world, local = env_world()
     if world > 1:
+        import datetime
         import torch
         import torch.distributed as dist
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             backend = os.environ.get("PMP_DIST_BACKEND") or ("nccl" if (device is not None and torch.cuda.is_available()) else "gloo")
             kw = {"device_id": device} if backend == "nccl" else {}
-            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+            t = float(os.environ.get("PMP_DIST_TIMEOUT_S", timeout_s or INIT_TIMEOUT_S))
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=t), **kw)
     return rank, world, local
+
+
+def preflight(device=None):
+    """First collective of a multi-rank job, with its content verified: every rank contributes (rank + 1) * [1, 2, 3, 4] to a
+    gather on rank 0 and a sum over all ranks.  Turns a broken RCCL / IPC setup (e.g. HSA_ENABLE_IPC_MODE_LEGACY unset) or a
+    duplicate-GPU placement into a readable error before any real work.  Returns {"ranks", "backend", "ms"}."""
+    import time
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return {"ranks": 1, "backend": None, "ms": 0.0}
+    rank, world, backend = dist.get_rank(), dist.get_world_size(), dist.get_backend()
+    dev = device if backend == "nccl" else torch.device("cpu")
+    t0 = time.perf_counter()
+    mine = (torch.arange(1, 5, dtype=torch.int64) * (rank + 1)).to(dev)
+    slots = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(world)] if rank == 0 else None
+    try:
+        dist.gather(mine, slots, dst=0)
+        total = mine.clone()
+        dist.all_reduce(total, op=dist.ReduceOp.SUM)
+        if backend == "nccl":
+            torch.cuda.synchronize(dev)
+    except Exception as e:      # noqa: BLE001 - whatever the backend raises, the message must name the likely causes
+        raise RuntimeError("rank %d/%d: the first %s collective failed (%s: %s).  Check: one GPU per rank, HSA_ENABLE_IPC_MODE_LEGACY=0 "
+                           "in the ranks' environment (dmabuf IPC), MASTER_ADDR=127.0.0.1" % (rank, world, backend, type(e).__name__, e)) from e
+    want = torch.arange(1, 5, dtype=torch.int64) * (world * (world + 1) // 2)
+    if not torch.equal(total.cpu(), want):
+        raise RuntimeError("rank %d/%d: %s all_reduce returned %s, expected %s" % (rank, world, backend, total.cpu().tolist(), want.tolist()))
+    if rank == 0:
+        for r, t in enumerate(slots):
+            if not torch.equal(t.cpu(), torch.arange(1, 5, dtype=torch.int64) * (r + 1)):
+                raise RuntimeError("rank 0: %s gather slot %d holds %s" % (backend, r, t.cpu().tolist()))
+    return {"ranks": world, "backend": backend, "ms": (time.perf_counter() - t0) * 1e3}
+
+
+def spawn_ranks(cmd, n, env_extra=None, capture_rank0=False, poll_s=0.05):
+    """Start n fresh rank processes of `cmd` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; the caller has made no GPU call -
+    a process that has initialised HIP must never be forked or re-executed) and watch ALL of them: the first rank that exits
+    non-zero ends the job - the others, which would sit in a collective until its timeout, are killed by PID - and its code is
+    returned.  capture_rank0: rank 0's stdout is collected (on a thread, so a full pipe never blocks it) and returned.
+    Returns (exit code, rank-0 stdout bytes or None)."""
+    import socket
+    import subprocess
+    import sys
+    import threading
+    import time
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
+    env.update(env_extra or {})
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen(list(cmd), env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                      stdout=subprocess.PIPE if (capture_rank0 and r == 0) else sys.stderr, stderr=sys.stderr))
+    chunks = []
+    reader = None
+    if capture_rank0:
+        reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+        reader.start()
+    rc = 0
+    try:
+        live = set(range(n))
+        while live and rc == 0:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0:
+                    rc = code
+                    print("rank %d exited with code %d: stopping the other ranks" % (r, code), file=sys.stderr, flush=True)
+                    break
+            if live and rc == 0:
+                time.sleep(poll_s)
+    except BaseException:
+        rc = rc or 1
+        raise
+    finally:
+        for p in procs:                                        # by PID, never by pattern
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except Exception:                                  # noqa: BLE001
+                pass
+        if reader is not None:
+            reader.join(timeout=30)
+    return rc, (b"".join(c for c in chunks if c) if capture_rank0 else None)
 
 
 def all_reduce_sum(arr, device=None):

@@ -106,7 +106,7 @@ def test_time_sta_columns_follow_the_component_not_the_flag_order():
 
 def test_rank_reads_only_its_frames(tmp_path, monkeypatch):
     """host I/O is the expected 8-GPU limiter, so a rank must read only the frames that hold its block range.
-    np.fromfile is wrapped to record every read; two ranks over a 5-frame sequence touch disjoint frame sets (one shared
+    The plane reader is wrapped to record every read; two ranks over a 5-frame sequence touch disjoint frame sets (one shared
     frame where the block boundary falls inside it) and together every frame."""
     from pmp_vvc_tip2023_amd import parallel
     w, h, fr = 192, 128, 5                                     # 3 x 2 blocks per frame
@@ -118,12 +118,12 @@ def test_rank_reads_only_its_frames(tmp_path, monkeypatch):
         for i in range(fr):
             f.write(y[i].tobytes()); f.write(u[i].tobytes()); f.write(v[i].tobytes())
     reads = []
-    real = np.fromfile
+    real = D._read_plane
 
-    def spy(fp, dtype=np.uint8, count=-1, **kw):
-        reads.append((fp.tell(), count))
-        return real(fp, dtype=dtype, count=count, **kw)
-    monkeypatch.setattr(D.np, "fromfile", spy)
+    def spy(fp, a):
+        reads.append((fp.tell(), a.size))
+        return real(fp, a)
+    monkeypatch.setattr(D, "_read_plane", spy)
     per_frame, n_total = 6, 6 * fr
     frame_bytes = w * h * 3 // 2
     touched = []

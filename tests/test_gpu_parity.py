@@ -630,8 +630,8 @@ def test_end_to_end_flags_vs_reference_logits(eng, g1, oracle_lib):
 
 
 def test_driver_two_ranks_equal_one_rank(tmp_path):
-    """The sharded driver (2 processes, blocks split between them, gather to rank 0) writes the same files as a single
-    process.  Both ranks share the one GPU of the test box, so the collective runs over gloo here; on a multi-GPU node the
+    """The sharded driver (2 processes: block rows split between them, each rank formats and pwrites its own rows, the ranks
+    exchange only byte counts) writes the same files as a single process.  Both ranks share the one GPU of the test box, so the collective runs over gloo here; on a multi-GPU node the
     same code path uses RCCL."""
     import os, socket, subprocess, sys
     from pmp_vvc_tip2023_amd import inference_qbd as D, synth
@@ -662,6 +662,17 @@ def test_driver_two_ranks_equal_one_rank(tmp_path):
     assert len(names) == 4 and names == sorted(os.listdir(d2))
     for nme in names:
         assert open(d1 / nme, "rb").read() == open(d2 / nme, "rb").read(), nme
+    # --emit gather: the older path (records gathered to rank 0, which writes alone) gives the same bytes
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(env, MASTER_PORT=str(port))
+    procs = [subprocess.Popen([sys.executable, "-m", "pmp_vvc_tip2023_amd.inference_qbd", "--jobID", "g", "--outDir", str(tmp_path / "og"), "--emit", "gather"] + common,
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    logs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    for nme in names:
+        assert open(d1 / nme, "rb").read() == open(tmp_path / "og" / "g" / "PartitionMat" / nme, "rb").read(), nme
     # the driver as its own launcher: --gpus 2 with no WORLD_SIZE in the environment spawns the two ranks itself
     env3 = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
     env3.update(PMP_DIST_BACKEND="gloo", PYTHONPATH=root)
@@ -720,6 +731,18 @@ def test_bench_launches_its_own_ranks(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["blocks_per_gpu"] == 32 and d["config"]["global_blocks"] == 64 and d["scaling"] == "weak"
     assert d["value"] > 0 and d["cpu_baseline"] is None
+    # the multi-GPU line says what the collective saw and cost ("if the N = 8 number disappoints there is nothing to say why")
+    m = d["multi_gpu"]
+    assert d["rccl_ranks"] == 2 and m["rccl_ranks"] == 2 and m["backend"] == "gloo" and m["gather_bytes_per_step"] == 2 * 32 * 1344
+    assert m["gather_ms"] >= 0 and len(m["ms_per_step_by_rank"]) == 2 and all(t > 0 for t in m["ms_per_step_by_rank"])
+    assert max(m["ms_per_step_by_rank"]) <= d["ms_per_step"] * 1.05 and m["preflight_ms"] > 0
+    assert "preflight ok: 2 ranks" in r.stderr
+    # the N = 1 line carries none of it
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "1", "--batch", "32", "--cpu-sample", "0",
+                         "--no-extras"], capture_output=True, text=True, timeout=900, env=env)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    d1 = json.loads(r1.stdout.strip())
+    assert "multi_gpu" not in d1 and "rccl_ranks" not in d1 and d1["n_gpus"] == 1
 
 
 def test_records_entry_point_equals_the_four_arrays(eng):
