@@ -29,8 +29,8 @@ def g3_sets():
         yield ("quant", cf, g["q_qt_cf%d" % cf].astype(np.float32), (g["q_bt64_cf%d" % cf] / 64.0).astype(np.float32),
                (g["q_dire64_cf%d" % cf] / 64.0).astype(np.float32), g["q_hor_cf%d" % cf], g["q_ver_cf%d" % cf],
                g["q_dout_cf%d" % cf], g["q_leaves_cf%d" % cf])
-        for t in ("r", "a"):
-            yield ({"r": "raw", "a": "adversarial"}[t], cf, g["%s_qt_cf%d" % (t, cf)].astype(np.float32),
+        for t in ("r", "a", "t"):
+            yield ({"r": "raw", "a": "adversarial", "t": "large-trees"}[t], cf, g["%s_qt_cf%d" % (t, cf)].astype(np.float32),
                    g["%s_bt_cf%d" % (t, cf)], g["%s_dire_cf%d" % (t, cf)], g["%s_hor_cf%d" % (t, cf)],
                    g["%s_ver_cf%d" % (t, cf)], g["%s_dout_cf%d" % (t, cf)], g["%s_leaves_cf%d" % (t, cf)])
 

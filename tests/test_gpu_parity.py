@@ -357,7 +357,7 @@ def test_map_to_partition_bit_exact_vs_reference_golden(eng, oracle_lib):
             oh, ov, od, _ = oracle_lib.map_to_partition(fixed[~same], bt[~same], dire[~same], cf)
             assert np.array_equal(h[~same], oh) and np.array_equal(v[~same], ov) and np.array_equal(d8[~same], od), (tag, cf)
             n_oracle += int((~same).sum())
-    assert n_gold >= 900 and n_oracle > 0
+    assert n_gold >= 1900 and n_oracle > 0        # 2204 reference triples; the few with a QT map the fix changes go against the oracle
 
 
 def test_eli_structural_error_bit_exact(eng):

@@ -18,7 +18,7 @@ def test_map_to_partition_bit_exact(oracle_lib):
         assert np.array_equal(d, dout), (tag, cf)
         assert np.array_equal(lv, leaves), (tag, cf)
         total += len(qt)
-    assert total >= 1000
+    assert total >= 2000          # >= 2000 reference-generated triples (2204), large trees for both chroma factors
 
 
 def test_eli_structural_error_bit_exact(oracle_lib):

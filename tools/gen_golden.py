@@ -144,7 +144,7 @@ def gen_g3():
     out = {"meta": np.array(META + "; inputs: q* = int16/64 quantised valid partitions + noise; r* = raw float32; a* = adversarial")}
     for cf in (1, 2):
         # quantised to multiples of 1/64: exact .5 ties and equal-error ties are frequent
-        parts = [synth.random_partition_batch(96, 1000 + cf * 10 + k, cf, s) for k, s in enumerate((0.0, 0.15, 0.3, 0.45))]
+        parts = [synth.random_partition_batch(224, 1000 + cf * 10 + k, cf, s) for k, s in enumerate((0.0, 0.15, 0.3, 0.45))]
         qt = np.concatenate([p[0] for p in parts]); bt = np.concatenate([p[1] for p in parts]); dr = np.concatenate([p[2] for p in parts])
         bt_q = np.rint(bt * 64).astype(np.int16); dr_q = np.rint(dr * 64).astype(np.int16)
         bt = (bt_q / 64.0).astype(np.float32); dr = (dr_q / 64.0).astype(np.float32)
@@ -155,7 +155,7 @@ def gen_g3():
                     "q_hor_cf%d" % cf: hor, "q_ver_cf%d" % cf: ver, "q_dout_cf%d" % cf: dout, "q_leaves_cf%d" % cf: leaves})
         print("G3 quantised cf", cf, len(qt), "leaves mean %.1f max %d" % (leaves.mean(), leaves.max()))
         # raw float32 noise
-        qt, bt, dr = synth.random_partition_batch(64, 2000 + cf, cf, 0.2)
+        qt, bt, dr = synth.random_partition_batch(128, 2000 + cf, cf, 0.2)
         hor, ver, dout = run_ref_m2p(qt, bt, dr, cf)
         ho, vo, do, leaves = P.map_to_partition(qt, bt, dr, cf)
         assert np.array_equal(hor, ho) and np.array_equal(ver, vo) and np.array_equal(dout, do), "oracle m2p mismatch (raw)"
@@ -170,6 +170,36 @@ def gen_g3():
         out.update({"a_qt_cf%d" % cf: qt[sl].astype(np.int8), "a_bt_cf%d" % cf: bt[sl], "a_dire_cf%d" % cf: dr[sl],
                     "a_hor_cf%d" % cf: hor, "a_ver_cf%d" % cf: ver, "a_dout_cf%d" % cf: dout, "a_leaves_cf%d" % cf: leaves})
         print("G3 adversarial cf", cf, len(hor), "leaves max", leaves.max())
+    # large candidate trees, both chroma factors (the adversarial set's largest tree has 6288 leaves for cf 1 but 1572 for cf 2):
+    # ambiguous maps - flat cumulative depths 1, 2, 3 (+ small noise, + random QT depth), directions near 0 so that every split mode
+    # survives can_split_mode_list - are searched with the (fast) oracle for the inputs with the most leaves; the REFERENCE then
+    # produces the expected outputs for the 24 largest per chroma factor.
+    for cf in (1, 2):
+        cq, cb, cd = [], [], []
+        for k in range(1500):
+            qd = int(rng.integers(0, 3))
+            q = np.full((8, 8), qd, np.float32)
+            if rng.random() < 0.3:
+                q[:4, :4] = min(qd + 1, 3)
+            base = np.stack([np.full((16, 16), qd * 0 + 1.0), np.full((16, 16), 2.0), np.full((16, 16), 3.0)]).astype(np.float32)
+            b = base + rng.normal(0, float(rng.choice([0.0, 0.05, 0.2])), base.shape).astype(np.float32)
+            d = rng.normal(0, float(rng.choice([0.0, 0.1, 0.3])), base.shape).astype(np.float32)
+            if rng.random() < 0.5:      # one quadrant with a definite structure, the rest ambiguous
+                d[:, :8, :8] = 1.0
+            cq.append(q); cb.append(b); cd.append(d)
+        cq, cb, cd = np.stack(cq), np.stack(cb), np.stack(cd)
+        _, _, _, leaves = P.map_to_partition(cq, cb, cd, cf)
+        top = np.argsort(-leaves, kind="stable")[:24]
+        qt, bt, dr = cq[top], cb[top], cd[top]
+        hor, ver, dout = run_ref_m2p(qt, bt, dr, cf)
+        ho, vo, do, leaves = P.map_to_partition(qt, bt, dr, cf)
+        assert np.array_equal(hor, ho) and np.array_equal(ver, vo) and np.array_equal(dout, do), "oracle m2p mismatch (large trees)"
+        out.update({"t_qt_cf%d" % cf: qt.astype(np.int8), "t_bt_cf%d" % cf: bt, "t_dire_cf%d" % cf: dr,
+                    "t_hor_cf%d" % cf: hor, "t_ver_cf%d" % cf: ver, "t_dout_cf%d" % cf: dout, "t_leaves_cf%d" % cf: leaves})
+        print("G3 large trees cf", cf, len(hor), "leaves min %d max %d" % (leaves.min(), leaves.max()))
+    total = sum(out[k].shape[0] for k in out if k.endswith(("_hor_cf1", "_hor_cf2")))
+    print("G3 total triples", total)
+    assert total >= 2000          # SURVEY 8(c) contract
     np.savez_compressed(os.path.join(OUT, "g3_m2p.npz"), **out)
 
 
