@@ -90,11 +90,24 @@ def open_library(path, subset=False):
     return lib
 
 
+def _torch_first():
+    """The PyTorch-ROCm wheel bundles its own libamdhip64 with the same soname as /opt/rocm's, so whichever copy is loaded first
+    serves the whole process.  With ours first, torch finds "No HIP GPUs" (seen on the GPU pool: the driver then silently kept its
+    blocks on the host).  Where torch is installed - it is the device allocator of the driver, bench and tests - it goes first."""
+    import sys
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+
+
 def load(path=None):
     """Load libpmp_hip.so (or, for tools/ and tests, the build at `path` - before anything else loaded the library).
     Fails loudly when the extension has not been built: there is no fallback path."""
     global _lib
     if _lib is None:
+        _torch_first()
         _lib = open_library(path or LIB_PATH)
     elif path is not None and os.path.abspath(path) != os.path.abspath(_lib._name):
         raise RuntimeError("a different build of the library is already loaded: %s" % _lib._name)

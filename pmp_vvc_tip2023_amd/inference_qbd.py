@@ -313,6 +313,9 @@ def inference_VVC_seqs(args):
             import torch
             if torch.cuda.is_available():
                 torch_dev = torch.device("cuda", dev_id)
+            else:
+                print("WARNING: torch sees no GPU although the library runs on one: blocks stay on the HOST (as with --hostBlocks)",
+                      file=sys.stderr, flush=True)
         except ImportError:
             torch_dev = None
     pinned = None
