@@ -409,7 +409,10 @@ int pmp_clear_saturation(pmp_ctx *c)
 int pmp_load_weights(pmp_ctx *c, int net_id, int qp, const float *blob, const pmp_tensor_desc *descs, int ndesc)
 {
     CHECK_CTX(c);
-    int rc = settle(c);     // a range-guard re-run of a call in flight must still find the weights it ran with
+    // REPLACING a net waits for the calls in flight (a range-guard re-run must still find the weights it ran with, and kernels may
+    // be reading them); ADDING one does not - the upload runs next to whatever the stream is doing, so a driver can load the next
+    // (component, QP) while the GPU works on this one
+    int rc = pmp_has_weights(c, net_id, qp) ? settle(c) : PMP_OK;
     if (rc != PMP_OK) return rc;
     return load_net_weights(c, net_id, qp, blob, descs, ndesc);
 }
@@ -430,7 +433,7 @@ int pmp_load_weights_file(pmp_ctx *c, int net_id, int qp, const char *path)
         for (int j = 0; j < 4; ++j) descs[i].shape[j] = wf.tensors[i].shape[j];
         descs[i].offset = wf.tensors[i].offset;
     }
-    if ((rc = settle(c)) != PMP_OK) return rc;
+    if (pmp_has_weights(c, net_id, qp) && (rc = settle(c)) != PMP_OK) return rc;   // see pmp_load_weights
     return load_net_weights(c, net_id, qp, wf.payload.data(), descs.data(), (int)descs.size());
 }
 

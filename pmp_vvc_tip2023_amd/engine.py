@@ -118,6 +118,14 @@ class Engine:
     def has_weights(self, net, qp):
         return bool(self.lib.pmp_has_weights(self.h, _lib.NET_IDS[net], int(qp)))
 
+    def check_available(self, comp, qp):
+        """Raise FileNotFoundError now if load(comp, qp) would: the driver loads weights lazily, next to the GPU's work, but a
+        missing model file must stop the job before any output (Inference_QBD.py:219-222)."""
+        for kind in ("Q", "MSBD"):
+            net = "%s_%s" % (comp, kind)
+            if not self.has_weights(net, qp):
+                W.find_net_weights(net, qp, self.weight_dir, allow_synthetic=self.allow_synthetic_mtt)
+
     def load(self, comp, qp, q_weights=None, msbd_weights=None):
         """Load both nets of (comp, qp); missing dicts are resolved by weights.load_net_weights()."""
         for kind, given in (("Q", q_weights), ("MSBD", msbd_weights)):

@@ -255,7 +255,7 @@ def _resolve(path, base):
 
 class Stages:
     """Wall-clock seconds the MAIN thread of this rank spent per stage (tools/driver_bench.py prints them)."""
-    NAMES = ("setup", "read_wait", "h2d_cut", "gpu_wait", "enqueue", "d2h", "emit_start", "emit_finish", "gather", "drain")
+    NAMES = ("setup", "weights", "read_wait", "h2d_cut", "first_enqueue", "gpu_wait", "enqueue", "d2h", "emit_start", "emit_finish", "gather", "drain", "teardown")
 
     def __init__(self):
         self.t = dict.fromkeys(self.NAMES, 0.0)
@@ -341,15 +341,24 @@ def inference_VVC_seqs(args):
     emitter = emit.ShardEmitter(rank, world, threads=args.emitThreads, device=device) if sharded else None
     writers = ThreadPoolExecutor(max_workers=4) if (rank == 0 and not sharded) else None
     pending = []
-    for comp in comps:  # weights once per (comp, qp), not once per sequence; a missing file raises here, before any output
+    # Weights once per (comp, qp), not once per sequence.  A missing file raises HERE, before any output - but only the first
+    # pass's nets are loaded now: the others go up while the GPU runs the pass before theirs (30 ms of packing each, hidden).
+    for comp in comps:
         for qp in qps:
-            eng.load(comp, qp)
-    if rank == 0:
-        for (net, qp), src in sorted(eng.provenance.items()):
-            print("weights %s QP%d: %s" % (net, qp, src), flush=True)
-        if any(str(src).startswith("synthetic") for src in eng.provenance.values()):
-            print("WARNING: MTT nets run on SYNTHETIC weights (--allowSyntheticMTT): the PartitionMat files are not usable "
-                  "for encoding", file=sys.stderr, flush=True)
+            eng.check_available(comp, qp)
+    announced = set()
+
+    def load_weights(comp, qp):
+        eng.load(comp, qp)
+        if rank == 0:
+            for (net, q), src in sorted(eng.provenance.items()):
+                if (net, q) not in announced:
+                    announced.add((net, q))
+                    print("weights %s QP%d: %s" % (net, q, src), flush=True)
+                    if str(src).startswith("synthetic") and "warned" not in announced:
+                        announced.add("warned")
+                        print("WARNING: MTT nets run on SYNTHETIC weights (--allowSyntheticMTT): the PartitionMat files are not usable "
+                              "for encoding", file=sys.stderr, flush=True)
 
     # ---- the reader: one thread, one sequence ahead.  A rank reads only the frames that hold its own block rows.
     def load_sequence(seq_id):
@@ -417,7 +426,15 @@ def inference_VVC_seqs(args):
         seqs_block_time[si] = time.perf_counter() - t0
 
         n_local = hi - lo
+        tw = time.perf_counter()
+        if passes:
+            load_weights(*passes[0])
+        tw = st.add("weights", tw)
         cur = dblk.enqueue(*passes[0]) if (dblk is not None and passes) else None
+        tw = st.add("first_enqueue", tw)               # the job's first pass also sizes and allocates the activation workspace
+        if len(passes) > 1:
+            load_weights(*passes[1])                   # next to pass 0 on the GPU
+            st.add("weights", tw)
         prev = None
         for k, (comp, qp) in enumerate(passes):
             comp_id = COMP_COLUMN[comp]                # Time_Sta columns: Luma first, whatever --comps lists
@@ -432,7 +449,11 @@ def inference_VVC_seqs(args):
                 if k + 1 < len(passes):                # the GPU starts on pass k+1 before the host touches pass k's records
                     cur = dblk.enqueue(*passes[k + 1])
                     tw = st.add("enqueue", tw)
+                    if k + 2 < len(passes):
+                        load_weights(*passes[k + 2])   # no-op after the first sequence
+                        tw = st.add("weights", tw)
             else:
+                load_weights(comp, qp)
                 local = parallel.pack_records(*eng.infer_postprocess(comp, qp, by, bu, bv)) if n_local else np.zeros((0, parallel.RECORD), np.uint8)
                 tw = st.add("gpu_wait", tw)
             seqs_net_time[si, qi, comp_id] = time.perf_counter() - t0
@@ -479,6 +500,7 @@ def inference_VVC_seqs(args):
         pending = []
         st.add("drain", tw)
         del dblk
+    tw = time.perf_counter()
     reader.shutdown(wait=True)
     if emitter is not None:
         emitter.close()
@@ -500,6 +522,7 @@ def inference_VVC_seqs(args):
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+    st.add("teardown", tw)
     return st
 
 

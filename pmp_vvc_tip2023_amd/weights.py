@@ -73,23 +73,31 @@ def ref_net_name(net):
     return comp + ("_Q" if kind == "Q" else "_BD")
 
 
-def load_net_weights(net, qp, weight_dir=None, allow_synthetic=False):
-    """Resolution order: <dir>/<Comp>_{Q,BD}_<qp>.pmpw, then .pkl (reference naming, Inference_QBD.py:219-220).  A missing
-    file is an error, as in the reference (Inference_QBD.py:219-222 dies on a missing model file) - unless
-    allow_synthetic=True, which for the MTT nets only (their files are absent from the reference mount)
-    falls back to the documented synthetic generator (seed = qp): tests, bench.py and smoke() ask for it explicitly, the
-    CLI driver only with --allowSyntheticMTT.  Returns (weights, provenance-string)."""
+def find_net_weights(net, qp, weight_dir=None, allow_synthetic=False):
+    """Where the weights of (net, qp) will come from, without reading them: ("pmpw" | "pkl", path) or ("synthetic", None).
+    Resolution order: <dir>/<Comp>_{Q,BD}_<qp>.pmpw, then .pkl (reference naming, Inference_QBD.py:219-220).  A missing file is an
+    error, as in the reference (Inference_QBD.py:219-222 dies on a missing model file) - unless allow_synthetic=True, which for the
+    MTT nets only (their files are absent from the reference mount) falls back to the documented synthetic generator
+    (seed = qp): tests, bench.py and smoke() ask for it explicitly, the CLI driver only with --allowSyntheticMTT."""
     d = weight_dir or default_weight_dir()
     stem = "%s_%d" % (ref_net_name(net), qp)
-    p = os.path.join(d, stem + ".pmpw")
-    if os.path.isfile(p):
-        return load_pmpw(p)[1], p
-    p = os.path.join(d, stem + ".pkl")
-    if os.path.isfile(p):
-        return load_pkl(p), p
+    for kind in ("pmpw", "pkl"):
+        p = os.path.join(d, stem + "." + kind)
+        if os.path.isfile(p):
+            return kind, p
     if net.endswith("_MSBD") and allow_synthetic:
-        from . import synth
-        return synth.synth_msbd_weights(net.split("_")[0], qp), "synthetic(seed=%d)" % qp
+        return "synthetic", None
     hint = " (MTT-net files are not part of the reference checkout; --allowSyntheticMTT / allow_synthetic=True runs on " \
            "documented synthetic weights instead)" if net.endswith("_MSBD") else ""
     raise FileNotFoundError("no weights for %s qp%d: neither %s.pmpw nor %s.pkl under %s%s" % (net, qp, stem, stem, d, hint))
+
+
+def load_net_weights(net, qp, weight_dir=None, allow_synthetic=False):
+    """Weights of (net, qp) as find_net_weights resolves them.  Returns (weights, provenance-string)."""
+    kind, p = find_net_weights(net, qp, weight_dir, allow_synthetic)
+    if kind == "pmpw":
+        return load_pmpw(p)[1], p
+    if kind == "pkl":
+        return load_pkl(p), p
+    from . import synth
+    return synth.synth_msbd_weights(net.split("_")[0], qp), "synthetic(seed=%d)" % qp

@@ -67,14 +67,14 @@ print("  main-thread stages (s): " + "  ".join("%s %.3f" % (k, st.t[k]) for k in
 print("  reader thread file I/O %.3f s (hidden behind the passes except for read_wait)" % st.prefetch_read)
 acc = sum(st.t.values())
 print("  accounted %.3f s of %.3f s" % (acc, dt))
-serial = {k: st.t[k] for k in ("setup", "read_wait", "h2d_cut", "d2h", "emit_start", "emit_finish", "gather", "drain")}
+serial = {k: st.t[k] for k in ("setup", "weights", "read_wait", "h2d_cut", "first_enqueue", "d2h", "emit_start", "emit_finish", "gather", "drain", "teardown")}
 host = sum(serial.values())
 print("  host-side serial share: %.3f s = %.1f %% of the job; per pass %.1f ms = %.2f of one GPU pass (%.1f ms)"
       % (host, 100 * host / dt, host / st.passes * 1e3, host / max(t_gpu, 1e-9), t_gpu / st.passes * 1e3))
-fixed = st.t["setup"] + st.t["enqueue"] + st.passes * 0.5e-3   # per rank whatever its share: context + weights, launches, ~0.5 ms per size all-reduce
+fixed = st.t["setup"] + st.t["teardown"] + st.t["first_enqueue"] + st.t["enqueue"] + st.passes * 0.5e-3   # per rank whatever its share: context + weights, launches, ~0.5 ms per size all-reduce
 for N in (2, 4, 8):
     if emit_mode == "sharded":     # every stage is per-rank work on 1/N of the rows
-        crit = (dt - st.t["enqueue"] - st.t["setup"]) / N + fixed
+        crit = (dt - fixed + st.passes * 0.5e-3) / N + fixed
     else:                          # rank 0 formats and writes everything: only the passes shrink
         crit = (st.t["gpu_wait"]) / N + (dt - st.t["gpu_wait"])
     print("  projected critical path at %d ranks: %.3f s  (x%.2f)" % (N, crit, dt / crit))
