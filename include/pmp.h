@@ -67,6 +67,11 @@ const char *pmp_last_error(const pmp_ctx *ctx);
 int pmp_create(int device_id, pmp_ctx **out);
 int pmp_destroy(pmp_ctx *ctx);
 
+/* pmp_destroy parks the context's activation workspace (up to 10 GB) for the next context created on the same device instead of
+ * freeing it: a large hipMalloc right after a hipFree of that size stalls for 0.5-1.4 s now and then on MI355X (the freed memory is
+ * still being cleared).  One parked buffer per device; pmp_trim() returns parked memory to the driver. */
+int pmp_trim(void);
+
 /* Use the caller's hipStream_t (e.g. torch's current stream); NULL restores the context's own stream. */
 int pmp_set_stream(pmp_ctx *ctx, void *hip_stream);
 int pmp_synchronize(pmp_ctx *ctx);

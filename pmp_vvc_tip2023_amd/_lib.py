@@ -31,6 +31,7 @@ SIGNATURES = {
     "pmp_last_error": (C.c_char_p, [_VP]),
     "pmp_create": (_I, [_I, C.POINTER(_VP)]),
     "pmp_destroy": (_I, [_VP]),
+    "pmp_trim": (_I, []),
     "pmp_set_stream": (_I, [_VP, _VP]),
     "pmp_synchronize": (_I, [_VP]),
     "pmp_set_chunk": (_I, [_VP, _I]),

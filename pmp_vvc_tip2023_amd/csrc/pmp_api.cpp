@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -24,8 +25,46 @@ int hip_fail(pmp_ctx *c, hipError_t e, const char *what)
     return set_err(c, PMP_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
 }
 
+// ---- parked workspaces.  On this pool a large hipMalloc that follows a hipFree of similar size stalls for 0.5-1.4 s now and then
+// (tools/probe/malloc_probe.py: the freed VRAM is still being cleared); a host that destroys a context and creates the next one -
+// one per sequence, one per encoder instance - would pay that for its 10 GB activation workspace every time.  pmp_destroy therefore
+// PARKS the workspace (one buffer per device, the larger one wins) and the next context on that device takes it over; pmp_trim()
+// gives parked memory back to the driver.
+namespace {
+std::mutex g_park_mutex;
+std::map<int, DevBuf> g_parked;   // device -> buffer
+}  // namespace
+
+static void park_workspace(int device, DevBuf &b)
+{
+    if (!b.p) return;
+    std::lock_guard<std::mutex> lk(g_park_mutex);
+    DevBuf &slot = g_parked[device];
+    if (slot.cap >= b.cap) { hipFree(b.p); }
+    else { if (slot.p) hipFree(slot.p); slot = b; }
+    b = DevBuf();
+}
+
+static bool take_parked(int device, size_t bytes, DevBuf &out)
+{
+    std::lock_guard<std::mutex> lk(g_park_mutex);
+    auto it = g_parked.find(device);
+    if (it == g_parked.end() || it->second.cap < bytes) return false;
+    out = it->second;
+    g_parked.erase(it);
+    return true;
+}
+
 static int ensure(pmp_ctx *c, DevBuf &b, size_t bytes)
 {
+    if (&b == &c->ws && bytes > b.cap && bytes >= ((size_t)64 << 20)) {   // a large activation workspace: a parked one of a destroyed context first (small ones are cheap to allocate and stay small)
+        DevBuf got;
+        if (take_parked(c->device, bytes, got)) {
+            if (b.p) hipFree(b.p);
+            b = got;
+            return PMP_OK;
+        }
+    }
     if (bytes <= b.cap) return PMP_OK;
     if (b.p) { hipFree(b.p); b.p = nullptr; b.cap = 0; }
     hipError_t e = hipMalloc(&b.p, bytes);
@@ -329,6 +368,7 @@ int pmp_destroy(pmp_ctx *c)
     ktime_drain(c);
     for (auto &kv : c->nets) free_net_weights(kv.second);
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
+    park_workspace(c->device, c->ws);
     DevBuf *bufs[] = {&c->ws, &c->d_in[0], &c->d_in[1], &c->d_in[2], &c->d_logit[0], &c->d_logit[1], &c->d_logit[2],
                       &c->d_out[0], &c->d_out[1], &c->d_out[2], &c->d_out[3], &c->d_frames[0], &c->d_frames[1], &c->d_frames[2]};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
@@ -336,6 +376,14 @@ int pmp_destroy(pmp_ctx *c)
     if (c->h_sat) hipHostFree(c->h_sat);
     hipStreamDestroy(c->own_stream);
     delete c;
+    return PMP_OK;
+}
+
+int pmp_trim(void)
+{
+    std::lock_guard<std::mutex> lk(g_park_mutex);
+    for (auto &kv : g_parked) { hipSetDevice(kv.first); if (kv.second.p) hipFree(kv.second.p); }
+    g_parked.clear();
     return PMP_OK;
 }
 
