@@ -107,7 +107,7 @@ static void ktime_drain(pmp_ctx *c)
     }
 }
 
-static const NetWeights *find_net(pmp_ctx *c, int net_id, int qp)
+static NetWeights *find_net(pmp_ctx *c, int net_id, int qp)
 {
     auto it = c->nets.find(net_id * 100 + qp);
     return (it == c->nets.end() || !it->second.loaded) ? nullptr : &it->second;
@@ -131,9 +131,11 @@ static int run_graph(pmp_ctx *c, F &&fwd)
     return fwd();
 }
 
-static int infer_passes(pmp_ctx *c, bool luma, const NetWeights &wq, const NetWeights &wb, const uint8_t *by, const uint8_t *bu,
+static int infer_passes(pmp_ctx *c, bool luma, NetWeights &wq, NetWeights &wb, const uint8_t *by, const uint8_t *bu,
                         const uint8_t *bv, int64_t n, float *qt, float *bt, float *dire)
 {
+    int rc0;     // weights are packed per datapath, on first use (the load packed the datapath that was current then)
+    if ((rc0 = ensure_datapath(c, wq, c->precision)) != PMP_OK || (rc0 = ensure_datapath(c, wb, c->precision)) != PMP_OK) return rc0;
     for (int64_t o = 0; o < n; o += c->chunk) {
         const int m = (int)((n - o) < c->chunk ? (n - o) : c->chunk);
         const uint8_t *y = by + o * 68 * 68;
@@ -224,8 +226,8 @@ static int infer_device_impl(pmp_ctx *c, int comp, int qp, const uint8_t *by, co
         return set_err(c, PMP_E_INVALID, "pmp_infer: null buffer or negative count");
     const bool luma = comp == PMP_LUMA;
     const int id_q = luma ? PMP_NET_LUMA_Q : PMP_NET_CHROMA_Q, id_b = luma ? PMP_NET_LUMA_MSBD : PMP_NET_CHROMA_MSBD;
-    const NetWeights *wq = find_net(c, id_q, qp);
-    const NetWeights *wb = find_net(c, id_b, qp);
+    NetWeights *wq = find_net(c, id_q, qp);
+    NetWeights *wb = find_net(c, id_b, qp);
     if (!wq || !wb) return set_err(c, PMP_E_NOWEIGHTS, "pmp_infer: weights for this (comp, qp) are not loaded");
     int rc = resolve_pending(c, false);          // earlier calls whose snapshot has landed by now: no wait
     if (rc != PMP_OK) return rc;
@@ -242,7 +244,7 @@ static int infer_device_impl(pmp_ctx *c, int comp, int qp, const uint8_t *by, co
     if (e == hipSuccess) e = hipEventRecord(ev, c->stream);
     if (e != hipSuccess) { c->event_pool.push_back(ev); return hip_fail(c, e, "saturation flag snapshot"); }
     c->pending.push_back(PendingCall{true, ev, slot, [=]() {
-        const NetWeights *rq = find_net(c, id_q, qp), *rb = find_net(c, id_b, qp);   // loading weights resolves first: still the same nets
+        NetWeights *rq = find_net(c, id_q, qp), *rb = find_net(c, id_b, qp);   // replacing a net settles first: still the same nets
         if (!rq || !rb) return set_err(c, PMP_E_NOWEIGHTS, "pmp_infer: weights vanished before the range-guard re-run");
         c->precision = PMP_PRECISION_BF16X6;        // three bf16 terms: fp32's exponent range, fp32-equivalent products
         const int r2 = infer_passes(c, luma, *rq, *rb, by, bu, bv, n, qt, bt, dire);

@@ -36,6 +36,11 @@ struct RBWeights {
 
 struct NetWeights {
     bool loaded = false;
+    int net_id = -1;
+    unsigned packed = 0;                               // bit p: the formats of datapath p (PMP_PRECISION_*) are on the device
+    std::vector<float> host;                           // the caller's fp32 tensors (OIHW), kept for the datapaths packed later
+    std::vector<std::string> names;
+    std::vector<pmp_tensor_desc> descs;                // offsets into `host`, names into `names`
     std::map<std::string, RBWeights> rb;
     float *stem_w = nullptr, *stem_b = nullptr;        // packed stem convs + 32 biases
     unsigned short *stem_wh = nullptr; int stem_k = 0; // f16x3 MFMA stem: fragment stream, scaled by 2^stem_k
@@ -134,6 +139,7 @@ int hip_fail(pmp_ctx *c, hipError_t e, const char *what);
 
 // weights_pack.cpp
 int load_net_weights(pmp_ctx *c, int net_id, int qp, const float *blob, const pmp_tensor_desc *descs, int ndesc);
+int ensure_datapath(pmp_ctx *c, NetWeights &w, int precision);   // packs the formats of `precision` if the net does not hold them yet
 void free_net_weights(NetWeights &w);
 
 // nets.cpp: forward graphs on device pointers (n <= chunk); all launches go to c->stream.

@@ -71,9 +71,12 @@ int need(pmp_ctx *c, const Blob &b, const std::string &name, std::initializer_li
     return PMP_OK;
 }
 
-int load_rb(pmp_ctx *c, const Blob &b, Uploader &up, const std::string &name, int cin, int cout, int k, bool direct)
+// mask: datapaths to pack for (bit = PMP_PRECISION_*).  A block that is already in the net keeps what it has; only the
+// missing formats are added (ensure_datapath).
+int load_rb(pmp_ctx *c, const Blob &b, Uploader &up, const std::string &name, int cin, int cout, int k, bool direct, unsigned mask)
 {
-    RBWeights r;
+    auto it = up.nw->rb.find(name);
+    RBWeights r = it != up.nw->rb.end() ? it->second : RBWeights();
     r.cin = cin; r.cout = cout; r.k = k; r.direct = direct;
     r.cin_pad = roundup16(cin); r.cout_pad = roundup16(cout);
     const float *w0, *w2, *wsc = nullptr;
@@ -81,24 +84,32 @@ int load_rb(pmp_ctx *c, const Blob &b, Uploader &up, const std::string &name, in
     if ((rc = need(c, b, name + ".left.0.weight", {cout, cin, k, k}, &w0))) return rc;
     if ((rc = need(c, b, name + ".left.2.weight", {cout, cout, k, k}, &w2))) return rc;
     if (cin != cout && (rc = need(c, b, name + ".shortcut.0.weight", {cout, cin, 1, 1}, &wsc))) return rc;
-    if (direct) {
-        if ((rc = up.upload(pack_plain(w0, cout, cin, k, k), &r.w0))) return rc;
-        if ((rc = up.upload(pack_plain(w2, cout, cout, k, k), &r.w2))) return rc;
-        if (wsc && (rc = up.upload(pack_plain(wsc, cout, cin, 1, 1), &r.wsc))) return rc;
+    if (direct) {       // 8x8 maps: the direct fp32 kernel on every datapath
+        if (!r.w0) {
+            if ((rc = up.upload(pack_plain(w0, cout, cin, k, k), &r.w0))) return rc;
+            if ((rc = up.upload(pack_plain(w2, cout, cout, k, k), &r.w2))) return rc;
+            if (wsc && (rc = up.upload(pack_plain(wsc, cout, cin, 1, 1), &r.wsc))) return rc;
+        }
     } else {
-        if ((rc = up.upload(pack_mfma(w0, cout, cin, k, k, r.cout_pad, r.cin_pad), &r.w0))) return rc;
-        if ((rc = up.upload(pack_mfma(w2, cout, cout, k, k, r.cout_pad, r.cout_pad), &r.w2))) return rc;
-        if (wsc && (rc = up.upload(pack_mfma(wsc, cout, cin, 1, 1, r.cout_pad, r.cin_pad), &r.wsc))) return rc;
-        if ((rc = up.upload16(pack_x6(w0, cout, cin, k, k, r.cout_pad, r.cin_pad), &r.w0x))) return rc;
-        if ((rc = up.upload16(pack_x6(w2, cout, cout, k, k, r.cout_pad, r.cout_pad), &r.w2x))) return rc;
-        if (wsc && (rc = up.upload16(pack_x6(wsc, cout, cin, 1, 1, r.cout_pad, r.cin_pad), &r.wscx))) return rc;
-        // fp16 split: the second conv and the 1x1 shortcut accumulate into one tile, so they share one scale
-        r.k0 = h2_scale_exp(w0, (size_t)cout * cin * k * k);
-        r.k2 = h2_scale_exp(w2, (size_t)cout * cout * k * k);
-        if (wsc) r.k2 = std::min(r.k2, h2_scale_exp(wsc, (size_t)cout * cin));
-        if ((rc = up.upload16(pack_h2(w0, cout, cin, k, k, r.cout_pad, r.cin_pad, r.k0), &r.w0h))) return rc;
-        if ((rc = up.upload16(pack_h2(w2, cout, cout, k, k, r.cout_pad, r.cout_pad, r.k2), &r.w2h))) return rc;
-        if (wsc && (rc = up.upload16(pack_h2(wsc, cout, cin, 1, 1, r.cout_pad, r.cin_pad, r.k2), &r.wsch))) return rc;
+        if ((mask & (1u << PMP_PRECISION_F32)) && !r.w0) {
+            if ((rc = up.upload(pack_mfma(w0, cout, cin, k, k, r.cout_pad, r.cin_pad), &r.w0))) return rc;
+            if ((rc = up.upload(pack_mfma(w2, cout, cout, k, k, r.cout_pad, r.cout_pad), &r.w2))) return rc;
+            if (wsc && (rc = up.upload(pack_mfma(wsc, cout, cin, 1, 1, r.cout_pad, r.cin_pad), &r.wsc))) return rc;
+        }
+        if ((mask & (1u << PMP_PRECISION_BF16X6)) && !r.w0x) {
+            if ((rc = up.upload16(pack_x6(w0, cout, cin, k, k, r.cout_pad, r.cin_pad), &r.w0x))) return rc;
+            if ((rc = up.upload16(pack_x6(w2, cout, cout, k, k, r.cout_pad, r.cout_pad), &r.w2x))) return rc;
+            if (wsc && (rc = up.upload16(pack_x6(wsc, cout, cin, 1, 1, r.cout_pad, r.cin_pad), &r.wscx))) return rc;
+        }
+        if ((mask & (1u << PMP_PRECISION_F16X3)) && !r.w0h) {
+            // fp16 split: the second conv and the 1x1 shortcut accumulate into one tile, so they share one scale
+            r.k0 = h2_scale_exp(w0, (size_t)cout * cin * k * k);
+            r.k2 = h2_scale_exp(w2, (size_t)cout * cout * k * k);
+            if (wsc) r.k2 = std::min(r.k2, h2_scale_exp(wsc, (size_t)cout * cin));
+            if ((rc = up.upload16(pack_h2(w0, cout, cin, k, k, r.cout_pad, r.cin_pad, r.k0), &r.w0h))) return rc;
+            if ((rc = up.upload16(pack_h2(w2, cout, cout, k, k, r.cout_pad, r.cout_pad, r.k2), &r.w2h))) return rc;
+            if (wsc && (rc = up.upload16(pack_h2(wsc, cout, cin, 1, 1, r.cout_pad, r.cin_pad, r.k2), &r.wsch))) return rc;
+        }
     }
     up.nw->rb[name] = r;
     return PMP_OK;
@@ -110,6 +121,7 @@ int load_head(pmp_ctx *c, const Blob &b, Uploader &up, const std::string &name, 
     int rc;
     if ((rc = need(c, b, name + ".weight", {cout, 8, 3, 3}, &w))) return rc;
     if ((rc = need(c, b, name + ".bias", {cout}, &bias))) return rc;
+    if (up.nw->head_w[slot]) return PMP_OK;
     if ((rc = up.upload(pack_plain(w, cout, 8, 3, 3), &up.nw->head_w[slot]))) return rc;
     return up.upload(std::vector<float>(bias, bias + cout), &up.nw->head_b[slot]);
 }
@@ -122,16 +134,15 @@ void free_net_weights(NetWeights &w)
     w = NetWeights();
 }
 
-int load_net_weights(pmp_ctx *c, int net_id, int qp, const float *blob, const pmp_tensor_desc *descs, int ndesc)
+// Packs what `mask` asks for into nw (formats it already holds are kept).  nw is left as it is on failure: the caller decides.
+static int build_net(pmp_ctx *c, int net_id, const Blob &b, NetWeights &nw, unsigned mask)
 {
-    if (net_id < 0 || net_id > 3 || !blob || !descs || ndesc <= 0) return set_err(c, PMP_E_INVALID, "pmp_load_weights: bad arguments");
     const bool luma = net_id == PMP_NET_LUMA_Q || net_id == PMP_NET_LUMA_MSBD;
     const bool msbd = net_id == PMP_NET_LUMA_MSBD || net_id == PMP_NET_CHROMA_MSBD;
-    Blob b{blob, descs, ndesc};
-    NetWeights nw;
     Uploader up{c, &nw};
     int rc = PMP_OK;
-    auto fail = [&](int code) { free_net_weights(nw); return code; };
+    const bool want_h2 = mask & (1u << PMP_PRECISION_F16X3);
+    auto fail = [&](int code) { return code; };
 
     if (!msbd) {
         // Model_QBD.py:60-76 (luma) / :158-174 (chroma)
@@ -139,16 +150,20 @@ int load_net_weights(pmp_ctx *c, int net_id, int qp, const float *blob, const pm
         const float *w, *bias;
         if ((rc = need(c, b, "conv_q1.weight", {32, cin, k1, k1}, &w))) return fail(rc);
         if ((rc = need(c, b, "conv_q1.bias", {32}, &bias))) return fail(rc);
-        if ((rc = up.upload(pack_plain(w, 32, cin, k1, k1), &nw.stem_w))) return fail(rc);
-        if ((rc = up.upload(std::vector<float>(bias, bias + 32), &nw.stem_b))) return fail(rc);
-        nw.stem_k = h2_scale_exp(w, (size_t)32 * cin * k1 * k1);
-        if ((rc = up.upload16(pack_stem_h2(w, cin, k1, nw.stem_k), &nw.stem_wh))) return fail(rc);
-        if ((rc = load_rb(c, b, up, "resblock_q1", 32, 64, kq, false))) return fail(rc);
-        if ((rc = load_rb(c, b, up, "resblock_q2", 64, 64, kq, false))) return fail(rc);
-        if ((rc = load_rb(c, b, up, "resblock_q3", 64, 32, 3, false))) return fail(rc);
-        if ((rc = load_rb(c, b, up, "resblock_q4", 128, 32, 3, false))) return fail(rc);
-        if ((rc = load_rb(c, b, up, "resblock_q5", 32, 32, 3, false))) return fail(rc);
-        if ((rc = load_rb(c, b, up, "resblock_q6", 32, 8, 3, true))) return fail(rc);   // 8x8 map: direct kernel
+        if (!nw.stem_w) {
+            if ((rc = up.upload(pack_plain(w, 32, cin, k1, k1), &nw.stem_w))) return fail(rc);
+            if ((rc = up.upload(std::vector<float>(bias, bias + 32), &nw.stem_b))) return fail(rc);
+        }
+        if (want_h2 && !nw.stem_wh) {
+            nw.stem_k = h2_scale_exp(w, (size_t)32 * cin * k1 * k1);
+            if ((rc = up.upload16(pack_stem_h2(w, cin, k1, nw.stem_k), &nw.stem_wh))) return fail(rc);
+        }
+        if ((rc = load_rb(c, b, up, "resblock_q1", 32, 64, kq, false, mask))) return fail(rc);
+        if ((rc = load_rb(c, b, up, "resblock_q2", 64, 64, kq, false, mask))) return fail(rc);
+        if ((rc = load_rb(c, b, up, "resblock_q3", 64, 32, 3, false, mask))) return fail(rc);
+        if ((rc = load_rb(c, b, up, "resblock_q4", 128, 32, 3, false, mask))) return fail(rc);
+        if ((rc = load_rb(c, b, up, "resblock_q5", 32, 32, 3, false, mask))) return fail(rc);
+        if ((rc = load_rb(c, b, up, "resblock_q6", 32, 8, 3, true, mask))) return fail(rc);   // 8x8 map: direct kernel
         if ((rc = load_head(c, b, up, "conv_q2", 1, 0))) return fail(rc);
     } else {
         // Model_QBD.py:101-125 (luma) / :199-223 (chroma)
@@ -160,16 +175,18 @@ int load_net_weights(pmp_ctx *c, int net_id, int qp, const float *blob, const pm
         if ((rc = need(c, b, "conv_b1_1.bias", {16}, &b1))) return fail(rc);
         if ((rc = need(c, b, "conv_b1_2.bias", {8}, &b2))) return fail(rc);
         if ((rc = need(c, b, "conv_b1_3.bias", {8}, &b3))) return fail(rc);
-        std::vector<float> sw = pack_plain(w1, 16, cin, k1, k1);
-        std::vector<float> t2 = pack_plain(w2, 8, cin, k2, k1), t3 = pack_plain(w3, 8, cin, k1, k2);
-        sw.insert(sw.end(), t2.begin(), t2.end());
-        sw.insert(sw.end(), t3.begin(), t3.end());
-        std::vector<float> sb(b1, b1 + 16);
-        sb.insert(sb.end(), b2, b2 + 8);
-        sb.insert(sb.end(), b3, b3 + 8);
-        if ((rc = up.upload(sw, &nw.stem_w))) return fail(rc);
-        if ((rc = up.upload(sb, &nw.stem_b))) return fail(rc);
-        {   // the three stem convs as one top-left anchored k1 x k1 conv (the 5x9 / 9x5 kernels zero-padded), for the MFMA stem
+        if (!nw.stem_w) {
+            std::vector<float> sw = pack_plain(w1, 16, cin, k1, k1);
+            std::vector<float> t2 = pack_plain(w2, 8, cin, k2, k1), t3 = pack_plain(w3, 8, cin, k1, k2);
+            sw.insert(sw.end(), t2.begin(), t2.end());
+            sw.insert(sw.end(), t3.begin(), t3.end());
+            std::vector<float> sb(b1, b1 + 16);
+            sb.insert(sb.end(), b2, b2 + 8);
+            sb.insert(sb.end(), b3, b3 + 8);
+            if ((rc = up.upload(sw, &nw.stem_w))) return fail(rc);
+            if ((rc = up.upload(sb, &nw.stem_b))) return fail(rc);
+        }
+        if (want_h2 && !nw.stem_wh) {   // the three stem convs as one top-left anchored k1 x k1 conv (the 5x9 / 9x5 kernels zero-padded), for the MFMA stem
             std::vector<float> w32((size_t)32 * cin * k1 * k1, 0.f);
             for (int co = 0; co < 16; ++co)
                 for (int i = 0; i < cin * k1 * k1; ++i) w32[(size_t)co * cin * k1 * k1 + i] = w1[(size_t)co * cin * k1 * k1 + i];
@@ -185,30 +202,75 @@ int load_net_weights(pmp_ctx *c, int net_id, int qp, const float *blob, const pm
             nw.stem_k = h2_scale_exp(w32.data(), w32.size());
             if ((rc = up.upload16(pack_stem_h2(w32.data(), cin, k1, nw.stem_k), &nw.stem_wh))) return fail(rc);
         }
-        if ((rc = load_rb(c, b, up, "trunk_M1.0", 32, 64, 5, false))) return fail(rc);
+        if ((rc = load_rb(c, b, up, "trunk_M1.0", 32, 64, 5, false, mask))) return fail(rc);
         for (int i = 1; i < 6; ++i)
-            if ((rc = load_rb(c, b, up, "trunk_M1." + std::to_string(i), 64, 64, 3, false))) return fail(rc);
+            if ((rc = load_rb(c, b, up, "trunk_M1." + std::to_string(i), 64, 64, 3, false, mask))) return fail(rc);
         for (int i = 0; i < 4; ++i)
-            if ((rc = load_rb(c, b, up, "trunk_M2." + std::to_string(i), 64, 64, 3, false))) return fail(rc);
+            if ((rc = load_rb(c, b, up, "trunk_M2." + std::to_string(i), 64, 64, 3, false, mask))) return fail(rc);
         for (const char *t : {"trunk_B1", "trunk_B2", "trunk_B3"}) {
-            if ((rc = load_rb(c, b, up, std::string(t) + ".0", 64, 32, 3, false))) return fail(rc);
-            if ((rc = load_rb(c, b, up, std::string(t) + ".1", 32, 16, 3, false))) return fail(rc);
-            if ((rc = load_rb(c, b, up, std::string(t) + ".2", 16, 8, 3, false))) return fail(rc);
+            if ((rc = load_rb(c, b, up, std::string(t) + ".0", 64, 32, 3, false, mask))) return fail(rc);
+            if ((rc = load_rb(c, b, up, std::string(t) + ".1", 32, 16, 3, false, mask))) return fail(rc);
+            if ((rc = load_rb(c, b, up, std::string(t) + ".2", 16, 8, 3, false, mask))) return fail(rc);
         }
         for (const char *t : {"trunk_Att1", "trunk_Att2"}) {
-            if ((rc = load_rb(c, b, up, std::string(t) + ".0", 3, 32, 3, false))) return fail(rc);
-            if ((rc = load_rb(c, b, up, std::string(t) + ".1", 32, 64, 3, false))) return fail(rc);
+            if ((rc = load_rb(c, b, up, std::string(t) + ".0", 3, 32, 3, false, mask))) return fail(rc);
+            if ((rc = load_rb(c, b, up, std::string(t) + ".1", 32, 64, 3, false, mask))) return fail(rc);
         }
         if ((rc = load_head(c, b, up, "conv_B1", 2, 0))) return fail(rc);
         if ((rc = load_head(c, b, up, "conv_B2", 2, 1))) return fail(rc);
         if ((rc = load_head(c, b, up, "conv_B3", 2, 2))) return fail(rc);
     }
+    nw.packed |= mask;
+    return PMP_OK;
+}
+
+// The caller's tensors are validated (names, shapes) and packed for the context's CURRENT datapath only; the fp32 originals are kept
+// on the host (1.8 - 4.3 MB per net) so that another datapath - a pmp_set_precision later, the bf16x6 re-run of the f16x3 range
+// guard - is packed when it is first used (ensure_datapath): loading costs a third of packing all three formats up front.
+int load_net_weights(pmp_ctx *c, int net_id, int qp, const float *blob, const pmp_tensor_desc *descs, int ndesc)
+{
+    if (net_id < 0 || net_id > 3 || !blob || !descs || ndesc <= 0) return set_err(c, PMP_E_INVALID, "pmp_load_weights: bad arguments");
+    NetWeights nw;
+    nw.net_id = net_id;
+    // own copy of the tensors (the caller keeps ownership of its blob): names, shapes and values, re-based to one host vector
+    size_t total = 0;
+    for (int i = 0; i < ndesc; ++i) {
+        if (!descs[i].name || descs[i].ndim < 0 || descs[i].ndim > 4 || descs[i].offset < 0) return set_err(c, PMP_E_INVALID, "pmp_load_weights: bad tensor descriptor");
+        size_t cnt = 1;
+        for (int j = 0; j < descs[i].ndim; ++j) { if (descs[i].shape[j] < 0) return set_err(c, PMP_E_INVALID, "pmp_load_weights: negative dimension"); cnt *= (size_t)descs[i].shape[j]; }
+        total += cnt;
+    }
+    nw.host.reserve(total);
+    nw.names.resize(ndesc);
+    nw.descs.resize(ndesc);
+    for (int i = 0; i < ndesc; ++i) {
+        size_t cnt = 1;
+        for (int j = 0; j < descs[i].ndim; ++j) cnt *= (size_t)descs[i].shape[j];
+        nw.names[i] = descs[i].name;
+        nw.descs[i] = descs[i];
+        nw.descs[i].offset = (int64_t)nw.host.size();
+        nw.host.insert(nw.host.end(), blob + descs[i].offset, blob + descs[i].offset + cnt);
+    }
+    for (int i = 0; i < ndesc; ++i) nw.descs[i].name = nw.names[i].c_str();
+    Blob b{nw.host.data(), nw.descs.data(), ndesc};
+    const int rc = build_net(c, net_id, b, nw, 1u << c->precision);
+    if (rc != PMP_OK) { free_net_weights(nw); return rc; }
     nw.loaded = true;
     const int key = net_id * 100 + qp;
     auto it = c->nets.find(key);
     if (it != c->nets.end()) free_net_weights(it->second);
-    c->nets[key] = nw;
+    NetWeights &slot = c->nets[key];
+    slot = std::move(nw);
+    for (size_t i = 0; i < slot.descs.size(); ++i) slot.descs[i].name = slot.names[i].c_str();   // the strings moved with the vector; re-point to be safe
     return PMP_OK;
+}
+
+int ensure_datapath(pmp_ctx *c, NetWeights &nw, int precision)
+{
+    const unsigned bit = 1u << precision;
+    if (nw.packed & bit) return PMP_OK;
+    Blob b{nw.host.data(), nw.descs.data(), (int)nw.descs.size()};
+    return build_net(c, nw.net_id, b, nw, bit);
 }
 
 }  // namespace pmp

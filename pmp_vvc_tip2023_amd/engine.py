@@ -133,6 +133,11 @@ class Engine:
             if given is None:
                 if self.has_weights(net, qp):
                     continue
+                kind, path = W.find_net_weights(net, qp, self.weight_dir, allow_synthetic=self.allow_synthetic_mtt)
+                if kind == "pmpw":      # the library's own reader: no copies through Python (pmp_load_weights_file)
+                    self._ck(self.lib.pmp_load_weights_file(self.h, _lib.NET_IDS[net], int(qp), path.encode()))
+                    self.provenance[(net, qp)] = path
+                    continue
                 given, src = W.load_net_weights(net, qp, self.weight_dir, allow_synthetic=self.allow_synthetic_mtt)
             else:
                 src = "caller"
