@@ -138,9 +138,9 @@ struct Graph {
                 b.x = t.p; b.w = r.w2; b.out = y.p;
                 b.N = n; b.H = H; b.W = W; b.Cin = r.cout; b.CinPad = t.C; b.Cout = r.cout; b.CoutPad = y.C;
                 b.KH = b.KW = r.k; b.relu = 1;
-                if (r.wsc) { b.x_sc = x.p; b.w_sc = r.wsc; b.Csc = r.cin; b.CscPad = x.C; }
+                if (r.has_sc) { b.x_sc = x.p; b.w_sc = r.wsc; b.Csc = r.cin; b.CscPad = x.C; }
                 else b.res = x.p;
-                { KScope ks(c, K_SMALL, 2.0 * px * r.cout * (r.cout * r.k * r.k + (r.wsc ? r.cin : 0))); check(launch_conv_direct(c->stream, b), "conv_direct"); }
+                { KScope ks(c, K_SMALL, 2.0 * px * r.cout * (r.cout * r.k * r.k + (r.has_sc ? r.cin : 0))); check(launch_conv_direct(c->stream, b), "conv_direct"); }
             }
             release(t);
             if (consume) release(x_in);
@@ -152,11 +152,11 @@ struct Graph {
         const bool x_dead = converted || consume;           // x's bytes are ours to reuse after this block
         Act t = alloc(r.cout, H, W, x6());
         const bool y_split = x6() && !out_f32;
-        const bool in_place = x_dead && !r.wsc && !pool && x.split == y_split && x.C == ((r.cout + 15) & ~15);
+        const bool in_place = x_dead && !r.has_sc && !pool && x.split == y_split && x.C == ((r.cout + 15) & ~15);
         Act y = in_place ? x : alloc(r.cout, pool ? H / 2 : H, pool ? W / 2 : W, y_split);
         conv(x, r, false, nullptr, nullptr, nullptr, false, t, 2.0 * px * r.cout * r.cin * r.k * r.k, kclass(r.k, r.cin, r.cout));
-        conv(t, r, true, r.wsc ? &x : nullptr, r.wsc ? nullptr : &x, gate, pool, y,
-             2.0 * px * r.cout * (r.cout * r.k * r.k + (r.wsc ? r.cin : 0)), kclass(r.k, r.cout, r.cout));
+        conv(t, r, true, r.has_sc ? &x : nullptr, r.has_sc ? nullptr : &x, gate, pool, y,
+             2.0 * px * r.cout * (r.cout * r.k * r.k + (r.has_sc ? r.cin : 0)), kclass(r.k, r.cout, r.cout));
         release(t);
         if (x_dead && !in_place) release(x);
         return y;

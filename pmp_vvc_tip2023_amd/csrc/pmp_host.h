@@ -32,6 +32,7 @@ struct RBWeights {
     unsigned short *w0h = nullptr, *w2h = nullptr, *wsch = nullptr;  // f16x3 split packing (conv_f16x3.hip), scaled by
     int k0 = 0, k2 = 0;                                               // 2^k0 (first conv) / 2^k2 (second conv + shortcut)
     bool direct = false;               // 8x8 layers run on the direct kernel
+    bool has_sc = false;               // 1x1 shortcut conv (cin != cout); the packed pointers exist per datapath, this flag always
 };
 
 struct NetWeights {

@@ -77,7 +77,7 @@ int load_rb(pmp_ctx *c, const Blob &b, Uploader &up, const std::string &name, in
 {
     auto it = up.nw->rb.find(name);
     RBWeights r = it != up.nw->rb.end() ? it->second : RBWeights();
-    r.cin = cin; r.cout = cout; r.k = k; r.direct = direct;
+    r.cin = cin; r.cout = cout; r.k = k; r.direct = direct; r.has_sc = cin != cout;
     r.cin_pad = roundup16(cin); r.cout_pad = roundup16(cout);
     const float *w0, *w2, *wsc = nullptr;
     int rc;
