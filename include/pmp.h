@@ -79,7 +79,8 @@ int pmp_synchronize(pmp_ctx *ctx);
 /* Blocks processed per pass; n > chunk is looped.  1..4096 (32-bit element offsets inside one activation tensor), default
  * 4096.  The activation workspace is sized for the blocks a pass actually runs, min(n, chunk), and tensors share memory once
  * their last consumer is enqueued: 2.5 MB per luma block on the default datapath (10 GB for a full 4096-block pass, 10 MB
- * for a 4-block call; bf16x6 3.75 MB, chroma 1.1 MB per block); it only grows, to what the largest pass so far needed.  pmp_get_workspace_bytes reports it. */
+ * for a 4-block call; bf16x6 3.75 MB, chroma 1.1 MB per block); it only grows, to what the largest pass so far needed.
+ * pmp_get_workspace_bytes reports that need (the buffer behind it may be a larger one taken over from a destroyed context, see pmp_trim). */
 int pmp_set_chunk(pmp_ctx *ctx, int blocks);
 int64_t pmp_get_workspace_bytes(const pmp_ctx *ctx);
 

@@ -124,6 +124,7 @@ static int run_graph(pmp_ctx *c, F &&fwd)
     int rc = fwd();
     if (rc != PMP_OK) return rc;
     if ((rc = ensure(c, c->ws, c->arena.peak)) != PMP_OK) return rc;
+    if (c->arena.peak > c->ws_need) c->ws_need = c->arena.peak;
     c->arena.base = static_cast<char *>(c->ws.p);
     c->arena.cap = c->ws.cap;
     c->arena.measuring = false;
@@ -407,7 +408,7 @@ int pmp_set_chunk(pmp_ctx *c, int blocks)
     return PMP_OK;
 }
 
-int64_t pmp_get_workspace_bytes(const pmp_ctx *c) { return c ? (int64_t)c->ws.cap : PMP_E_INVALID; }
+int64_t pmp_get_workspace_bytes(const pmp_ctx *c) { return c ? (int64_t)c->ws_need : PMP_E_INVALID; }
 
 int pmp_set_precision(pmp_ctx *c, int mode)
 {

@@ -123,7 +123,8 @@ struct pmp_ctx {
     int64_t sat_reruns = 0;                // calls re-run on the bf16x6 datapath
     std::map<int, pmp::NetWeights> nets;  // key = net_id * 100 + qp
     pmp::Arena arena;
-    pmp::DevBuf ws;                        // activation workspace
+    pmp::DevBuf ws;                        // activation workspace (its own, or a larger one parked by a destroyed context)
+    size_t ws_need = 0;                    // what the largest pass so far needed of it (pmp_get_workspace_bytes)
     pmp::DevBuf d_in[3], d_logit[3], d_out[4], d_frames[3];  // staging for the host-pointer entry points
     // kernel-class timing
     uint32_t kmask = 0;

@@ -28,8 +28,18 @@ with open(os.path.join(inp, "table.txt"), "w") as tf:
         tf.write("%s,%s,%d,%d,%d,30\n" % (name, fn, W, H, F))
         open(os.path.join(cfg, name + ".cfg"), "w").write("InputFile : %s\nInputBitDepth : 8\n" % fn)
     tf.write("#end!!!!\n")
+# a CTU_Models-style directory as a production run has it: the shipped QT nets and - standing in for the trained *_BD_* files the
+# reference checkout lacks - the documented synthetic MTT nets, all as .pmpw files, so that loading goes through the library's reader
+import shutil
+from pmp_vvc_tip2023_amd import weights as Wt
+models = os.path.join(tmp, "CTU_Models")
+os.makedirs(models)
+for comp in ("Luma", "Chroma"):
+    for qp in (22, 27, 32, 37):
+        shutil.copy(os.path.join(Wt.default_weight_dir(), "%s_Q_%d.pmpw" % (comp, qp)), models)
+        Wt.save_pmpw(os.path.join(models, "%s_BD_%d.pmpw" % (comp, qp)), comp + "_MSBD", qp, synth.synth_msbd_weights(comp, qp), source="synthetic(seed=%d)" % qp)
 args = ["--jobID", "b", "--inputDir", inp, "--outDir", out, "--seqTable", "table.txt", "--cfgDir", cfg, "--ssRatio", "1",
-        "--startSeqID", "0", "--seqNum", str(nseq), "--allowSyntheticMTT", "--emit", emit_mode]
+        "--startSeqID", "0", "--seqNum", str(nseq), "--modelDir", models, "--emit", emit_mode]
 D.main(args)            # warm-up (weights, workspace, first-touch, page cache)
 t0 = time.time()
 D.main(args)
