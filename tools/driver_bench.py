@@ -81,10 +81,15 @@ serial = {k: st.t[k] for k in ("setup", "weights", "read_wait", "h2d_cut", "firs
 host = sum(serial.values())
 print("  host-side serial share: %.3f s = %.1f %% of the job; per pass %.1f ms = %.2f of one GPU pass (%.1f ms)"
       % (host, 100 * host / dt, host / st.passes * 1e3, host / max(t_gpu, 1e-9), t_gpu / st.passes * 1e3))
-fixed = st.t["setup"] + st.t["teardown"] + st.t["first_enqueue"] + st.t["enqueue"] + st.passes * 0.5e-3   # per rank whatever its share: context + weights, launches, ~0.5 ms per size all-reduce
+# N ranks, sharded emission: every rank does 1/N of the rows (passes, copies, formatting, writes) but ALL of the per-job work: context,
+# the first pass's weights (exposed), the other passes' weights and the launches (hidden behind its GPU passes while those last longer)
+w_first = st.t["weights"] / max(st.passes, 1)
+exposed = st.t["setup"] + st.t["teardown"] + st.t["first_enqueue"] + w_first + st.passes * 0.5e-3      # ~0.5 ms per size all-reduce
+hidden = st.t["weights"] - w_first + st.t["enqueue"]
+rows = sum(st.t[k] for k in ("read_wait", "h2d_cut", "gpu_wait", "d2h", "emit_start", "emit_finish", "drain"))
 for N in (2, 4, 8):
-    if emit_mode == "sharded":     # every stage is per-rank work on 1/N of the rows
-        crit = (dt - fixed + st.passes * 0.5e-3) / N + fixed
+    if emit_mode == "sharded":
+        crit = exposed + max(rows / N, hidden)
     else:                          # rank 0 formats and writes everything: only the passes shrink
-        crit = (st.t["gpu_wait"]) / N + (dt - st.t["gpu_wait"])
-    print("  projected critical path at %d ranks: %.3f s  (x%.2f)" % (N, crit, dt / crit))
+        crit = st.t["gpu_wait"] / N + (dt - st.t["gpu_wait"])
+    print("  projected critical path at %d ranks: %.3f s  (x%.2f)%s" % (N, crit, dt / crit, "  [weight loading is the longer leg]" if emit_mode == "sharded" and hidden > rows / N else ""))
