@@ -82,6 +82,40 @@ def main():
         if n:
             assert lib.pmp_format_partition_text(F, H, W, hor.ctypes.data, ver.ctypes.data, q8.ctypes.data, d8.ctypes.data, small,
                                                  max(int(need) // 2, 1)) == -1
+    # 3b. block-row formatters of the sharded emission (pmp_format_partition_rows[_records], pmp_tile_partition_rows_records): any run
+    #     of rows is the frame formatter on that slice; exact-size buffers; sizes-only calls
+    from pmp_vvc_tip2023_amd import parallel
+    for W_, nbr, wild in ((200, 5, True), (64, 1, False), (136, 3, True), (640, 2, False)):
+        bw = W_ // 64
+        n = nbr * bw
+        if wild:
+            hor = rng.integers(0, 256, (n, 16, 16)).astype(np.uint8); q8 = rng.integers(0, 256, (n, 8, 8)).astype(np.uint8)
+            d8 = rng.integers(-128, 128, (n, 3, 16, 16)).astype(np.int8)
+        else:
+            hor = rng.integers(0, 2, (n, 16, 16)).astype(np.uint8); q8 = rng.integers(0, 4, (n, 8, 8)).astype(np.uint8)
+            d8 = rng.integers(-1, 2, (n, 3, 16, 16)).astype(np.int8)
+        ver = rng.integers(0, 2, (n, 16, 16)).astype(np.uint8)
+        rec = parallel.pack_records(hor, ver, q8, d8)
+        for a, b in ((0, nbr), (nbr - 1, nbr), (0, 1)):
+            sl = slice(a * bw, b * bw)
+            buf, sizes = engine.format_partition_rows_records(W_, b - a, rec[sl])
+            want = engine.format_partition_text(1, 64 * (b - a), W_, hor[sl], ver[sl], q8[sl], d8[sl])
+            assert buf.raw[:int(sizes.sum())] == want
+            sz2 = np.zeros((b - a, 6), np.int64)
+            need = lib.pmp_format_partition_rows(W_, b - a, hor[sl].ctypes.data, ver[sl].ctypes.data, q8[sl].ctypes.data, d8[sl].ctypes.data, None, 0,
+                                                 sz2.ctypes.data)
+            assert need == len(want) and np.array_equal(sz2, sizes)
+            out = C.create_string_buffer(max(int(need), 1))
+            assert lib.pmp_format_partition_rows(W_, b - a, hor[sl].ctypes.data, ver[sl].ctypes.data, q8[sl].ctypes.data, d8[sl].ctypes.data, out, need,
+                                                 None) == need and out.raw[:need] == want
+            if need > 8:
+                small = C.create_string_buffer(int(need) - 7)
+                assert lib.pmp_format_partition_rows_records(W_, b - a, np.ascontiguousarray(rec[sl]).ctypes.data, small, need - 7, None) == -1
+            oh, ov, oq, od = engine.tile_partition_rows_records(W_, b - a, rec[sl])
+            th, tv, tq, td = engine.tile_partition_maps(1, 64 * (b - a), W_, hor[sl], ver[sl], q8[sl], d8[sl])
+            assert np.array_equal(oh, th[0]) and np.array_equal(ov, tv[0]) and np.array_equal(oq, tq[0]) and np.array_equal(od, td[0])
+    assert lib.pmp_format_partition_rows_records(64, 1, None, None, 0, None) == -1
+    assert lib.pmp_tile_partition_rows_records(64, 1, None, None, None, None, None) == -1
     # 4. error paths
     assert lib.pmp_tile_partition_maps(1, 64, 64, None, None, None, None, None, None, None, None) == -1
     assert lib.pmp_write_partition_file(None, 1, 64, 64, None, None, None, None) == -1

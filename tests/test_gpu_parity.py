@@ -84,6 +84,8 @@ def _oracle_512(comp, qp):
     from pmp_vvc_tip2023_amd import synth, weights as W
     key = (comp, qp)
     if key not in _ORACLE_512:
+        import os
+        torch.set_num_threads(min(16, os.cpu_count() or 1))   # torch's CPU convs stop scaling there (bench.py calibrates the same): 4x faster on the GPU box
         n = 512
         y, u, v = synth.recipe_r_blocks(n, 1000 + qp + (7 if comp == "Chroma" else 0))
         luma = comp == "Luma"

@@ -15,3 +15,11 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OU
 rocprofv3 --pmc WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1
 find $OUT -name "*.csv" | head -50
 ls -la $OUT
+# memory-path counters of every conv kernel in the step (the 5x5 + shortcut instantiation gets the treatment the 3x3 kernel got)
+for set in "TD_TD_BUSY_sum TD_TC_STALL_sum" \
+           "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" \
+           "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum" \
+           "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum"; do
+  name=$(echo $set | cut -d' ' -f1)
+  timeout -k 5 300 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_mem_$name -- $BENCH > $OUT/pmc_mem_$name.log 2>&1
+done
