@@ -696,6 +696,15 @@ int pmp_debug_set_conv_variant(int variant)
 #endif
 }
 
+int pmp_debug_set_winograd(pmp_ctx *c, int on)
+{
+    CHECK_CTX(c);
+    const int rc = settle(c);
+    if (rc != PMP_OK) return rc;
+    c->winograd = on ? 1 : 0;
+    return PMP_OK;
+}
+
 int pmp_debug_conv_bench(pmp_ctx *c, int n, int h, int w, int cin, int cout, int k, int iters, double *ms_f32, double *ms_x6,
                          double *max_abs_diff, double *max_abs_ref)
 {
@@ -713,18 +722,25 @@ int pmp_debug_conv_bench(pmp_ctx *c, int n, int h, int w, int cin, int cout, int
     const bool h2 = c->precision == PMP_PRECISION_F16X3;   // the split leg follows the context's datapath
     const int kexp = h2_scale_exp(hw.data(), hw.size());
     std::vector<unsigned short> wx = h2 ? pack_h2(hw.data(), cout, cin, k, k, cout, cin, kexp) : pack_x6(hw.data(), cout, cin, k, k, cout, cin);
+    const bool wino = h2 && c->winograd && k == 3 && cin == 64 && cout == 64;     // the Winograd-x form of this layer (conv_f16x3_wx.hip)
+    int kexp_w = 0;
+    std::vector<unsigned short> ww;
+    if (wino) ww = pack_h2_wx(hw.data(), &kexp_w);
+    unsigned short *dww = nullptr;
     float *dx = nullptr, *dy = nullptr, *dy2 = nullptr, *dwp = nullptr;
     unsigned short *dxs = nullptr, *dys = nullptr, *dwx = nullptr;
     hipError_t e = hipSuccess;
     auto A = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
     A((void **)&dx, nx * 4); A((void **)&dy, ny * 4); A((void **)&dy2, ny * 4); A((void **)&dwp, wp.size() * 4);
     A((void **)&dxs, nx * 6); A((void **)&dys, ny * 6); A((void **)&dwx, wx.size() * 2);
+    if (wino) A((void **)&dww, ww.size() * 2);
     int rc = PMP_OK;
     if (e != hipSuccess) rc = hip_fail(c, e, "hipMalloc(conv bench)");
     if (rc == PMP_OK) {
         hipMemcpy(dx, hx.data(), nx * 4, hipMemcpyHostToDevice);
         hipMemcpy(dwp, wp.data(), wp.size() * 4, hipMemcpyHostToDevice);
         hipMemcpy(dwx, wx.data(), wx.size() * 2, hipMemcpyHostToDevice);
+        if (wino) hipMemcpy(dww, ww.data(), ww.size() * 2, hipMemcpyHostToDevice);
         ConvMfmaArgs a{};
         a.x = dx; a.w = dwp; a.out = dy; a.N = n; a.H = h; a.W = w; a.Cin = cin; a.Cout = cout; a.KH = a.KW = k; a.relu = 1;
         ConvX6Args b{};
@@ -732,6 +748,7 @@ int pmp_debug_conv_bench(pmp_ctx *c, int n, int h, int w, int cin, int cout, int
         b.N = n; b.H = h; b.W = w; b.Cin = cin; b.Cout = cout; b.KH = b.KW = k; b.relu = 1;
         b.out_scale = std::ldexp(1.f, -kexp);
         b.zeros = c->d_sat + 16;
+        if (wino) { b.w_wx = dww; b.wx_out_scale = std::ldexp(1.f, -kexp_w); }
         auto launch_split = [&]() { return h2 ? launch_conv_h2(c->stream, b) : launch_conv_x6(c->stream, b); };
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
@@ -816,7 +833,7 @@ int pmp_debug_conv_bench(pmp_ctx *c, int n, int h, int w, int cin, int cout, int
         hipEventDestroy(e0); hipEventDestroy(e1);
         if (e != hipSuccess) rc = hip_fail(c, e, "conv bench");
     }
-    for (void *p : {(void *)dx, (void *)dy, (void *)dy2, (void *)dwp, (void *)dxs, (void *)dys, (void *)dwx}) if (p) hipFree(p);
+    for (void *p : {(void *)dx, (void *)dy, (void *)dy2, (void *)dwp, (void *)dxs, (void *)dys, (void *)dwx, (void *)dww}) if (p) hipFree(p);
     return rc;
 }
 

@@ -47,6 +47,7 @@ struct ConvX6Args {
     float out_scale;           // f16x3 only: 1/S of the power-of-two weight scaling (conv_f16x3.hip)
     unsigned *sat;             // f16x3 only: sticky flag raised when a stored activation exceeded the fp16 range (may be nullptr)
     const void *zeros;         // f16x3 only: >= 16 zero bytes in device memory (source of out-of-image halo pieces, conv_f16x3_t32.hip)
+    const unsigned short *w_wx; float wx_out_scale;   // f16x3, 3x3 64->64 only: Winograd-x weight stream (pack_h2_wx) and its 1/S (conv_f16x3_wx.hip)
 };
 hipError_t launch_conv_x6(hipStream_t s, const ConvX6Args &a);
 hipError_t launch_f32_to_split3(hipStream_t s, const float *x, unsigned short *out, size_t n, size_t plane_stride);
@@ -59,6 +60,9 @@ hipError_t launch_conv_h2(hipStream_t s, const ConvX6Args &a);
 bool conv_h2_t32_applicable(const ConvX6Args &a);
 hipError_t launch_conv_h2_t32(hipStream_t s, const ConvX6Args &a);
 #endif
+// conv_f16x3_wx.hip: the 3x3 64->64 convolution with a 1-D Winograd F(2,3) transform along x (1.5x fewer MFMAs)
+bool conv_h2_wx_applicable(const ConvX6Args &a);
+hipError_t launch_conv_h2_wx(hipStream_t s, const ConvX6Args &a);
 hipError_t launch_f32_to_split2(hipStream_t s, const float *x, unsigned short *out, size_t n, size_t plane_stride, unsigned *sat = nullptr);
 hipError_t launch_split2_to_f32(hipStream_t s, const unsigned short *x, float *out, size_t n, size_t plane_stride);
 

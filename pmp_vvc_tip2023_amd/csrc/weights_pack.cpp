@@ -109,6 +109,10 @@ int load_rb(pmp_ctx *c, const Blob &b, Uploader &up, const std::string &name, in
             if ((rc = up.upload16(pack_h2(w0, cout, cin, k, k, r.cout_pad, r.cin_pad, r.k0), &r.w0h))) return rc;
             if ((rc = up.upload16(pack_h2(w2, cout, cout, k, k, r.cout_pad, r.cout_pad, r.k2), &r.w2h))) return rc;
             if (wsc && (rc = up.upload16(pack_h2(wsc, cout, cin, 1, 1, r.cout_pad, r.cin_pad, r.k2), &r.wsch))) return rc;
+            if (k == 3 && cin == 64 && cout == 64) {     // the trunk blocks: Winograd-x form of both convolutions
+                if ((rc = up.upload16(pack_h2_wx(w0, &r.k0w), &r.w0w))) return rc;
+                if ((rc = up.upload16(pack_h2_wx(w2, &r.k2w), &r.w2w))) return rc;
+            }
         }
     }
     up.nw->rb[name] = r;
