@@ -671,8 +671,8 @@ __device__ __forceinline__ void h2_epilogue(const ConvX6Args &a, f32x4 (&acc)[Wa
             u32x4 p = ra[m >> 1][slot], q = rbv[m >> 1][slot];
             rows16_swap(p);
             rows16_swap(q);
-            acc[m][nt] = acc[m][nt] * inv_scale + (h2_lo4(p) + h2_lo4(q));        // undo the power-of-two weight scaling (exact)
-            acc[m + 1][nt] = acc[m + 1][nt] * inv_scale + (h2_hi4(p) + h2_hi4(q));
+            acc[m][nt] = acc[m][nt] * inv_scale + h2_sum4_lo(p, q);        // undo the power-of-two weight scaling (exact)
+            acc[m + 1][nt] = acc[m + 1][nt] * inv_scale + h2_sum4_hi(p, q);
         }
     };
     if (a.res) {

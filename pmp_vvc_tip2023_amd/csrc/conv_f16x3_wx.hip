@@ -65,30 +65,6 @@ __device__ __forceinline__ void wx_load(const WxItem &it, const unsigned short *
     }
 }
 
-// ---- mixed-precision FMA (v_fma_mix*): an fp16 operand enters an fp32 FMA without a conversion instruction, and the fp32 result
-// can be written as fp16.  Two uses: (i) an activation is carried as two fp16 terms, value = h0 + h1: ONE instruction per value
-// instead of two conversions and an add; (ii) the second term of a split, h1 = fp16(v - h0): one instruction instead of a
-// conversion back and a subtraction.  hipcc folds fma(x, 1, y) into an add and never emits these, hence the asm.
-__device__ __forceinline__ float wx_sum_lo(unsigned h0, unsigned h1)   // (float)lo16(h0) + (float)lo16(h1)
-{
-    float d;
-    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(h0), "v"(h1));
-    return d;
-}
-__device__ __forceinline__ float wx_sum_hi(unsigned h0, unsigned h1)
-{
-    float d;
-    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(h0), "v"(h1));
-    return d;
-}
-// (v, w) -> packed fp16 pair of their first terms and of the remainders: p = (f16(v), f16(w)), q = (f16(v - lo(p)), f16(w - hi(p)))
-__device__ __forceinline__ void wx_split_pair(float v, float w, unsigned &p, unsigned &q)
-{
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p) : "v"(v), "v"(w));
-    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-        : "=&v"(q) : "v"(v), "v"(w), "v"(p));
-}
-
 // r -> V0..V3 of 8 channels -> two fp16 terms each -> LDS.  No clamp and no range tracking here: |V| can reach twice an activation,
 // so a V beyond the fp16 range becomes inf / NaN, every output of the tile that depends on it becomes NaN, and the epilogue's
 // NaN-aware tracking (split3.h: sat_bits) raises the context's flag - the call is then re-run on bf16x6 like any other saturation.
@@ -99,7 +75,7 @@ __device__ __forceinline__ void wx_transform_store(unsigned it_lds, const u32x4 
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) d[k][i] = (f32x2){wx_sum_lo(r[2 * k][i], r[2 * k + 1][i]), wx_sum_hi(r[2 * k][i], r[2 * k + 1][i])};
+        for (int i = 0; i < 4; ++i) d[k][i] = (f32x2){h2_sum_lo(r[2 * k][i], r[2 * k + 1][i]), h2_sum_hi(r[2 * k][i], r[2 * k + 1][i])};
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         u32x4 h0, h1;
@@ -107,7 +83,7 @@ __device__ __forceinline__ void wx_transform_store(unsigned it_lds, const u32x4 
         for (int i = 0; i < 4; ++i) {
             const f32x2 v = p == 0 ? d[0][i] - d[2][i] : p == 1 ? d[1][i] + d[2][i] : p == 2 ? d[2][i] - d[1][i] : d[1][i] - d[3][i];
             unsigned hp, hq;
-            wx_split_pair(v.x, v.y, hp, hq);
+            h2_split_pair_noclamp(v.x, v.y, hp, hq);
             h0[i] = hp; h1[i] = hq;
         }
         *reinterpret_cast<u32x4 *>(buf + it_lds + p * 256) = h0;
@@ -337,8 +313,8 @@ __global__ __launch_bounds__(256, 2) void conv_h2_wx_kernel(ConvX6Args a)
                 u32x4 ra = nt == 0 ? rres[2 * rp] : rn[2 * rp], rb = nt == 0 ? rres[2 * rp + 1] : rn[2 * rp + 1];
                 rows16_swap(ra);
                 rows16_swap(rb);
-                y0 += (f32x4){wx_sum_lo(ra.x, rb.x), wx_sum_hi(ra.x, rb.x), wx_sum_lo(ra.y, rb.y), wx_sum_hi(ra.y, rb.y)};
-                y1 += (f32x4){wx_sum_lo(ra.z, rb.z), wx_sum_hi(ra.z, rb.z), wx_sum_lo(ra.w, rb.w), wx_sum_hi(ra.w, rb.w)};
+                y0 += (f32x4){h2_sum_lo(ra.x, rb.x), h2_sum_hi(ra.x, rb.x), h2_sum_lo(ra.y, rb.y), h2_sum_hi(ra.y, rb.y)};
+                y1 += (f32x4){h2_sum_lo(ra.z, rb.z), h2_sum_hi(ra.z, rb.z), h2_sum_lo(ra.w, rb.w), h2_sum_hi(ra.w, rb.w)};
             }
             omax = sat_amax4(sat_amax4(omax, y0), y1);      // before the ReLU: it would swallow a NaN (see wx_transform_store)
             if (a.relu) {
@@ -346,10 +322,10 @@ __global__ __launch_bounds__(256, 2) void conv_h2_wx_kernel(ConvX6Args a)
                 y1.x = fmaxf(y1.x, 0.f); y1.y = fmaxf(y1.y, 0.f); y1.z = fmaxf(y1.z, 0.f); y1.w = fmaxf(y1.w, 0.f);
             }
             unsigned p0, q0, p1, q1, p2, q2, p3, q3;
-            wx_split_pair(y0.x, y0.y, p0, q0);
-            wx_split_pair(y0.z, y0.w, p1, q1);
-            wx_split_pair(y1.x, y1.y, p2, q2);
-            wx_split_pair(y1.z, y1.w, p3, q3);
+            h2_split_pair(y0.x, y0.y, p0, q0);
+            h2_split_pair(y0.z, y0.w, p1, q1);
+            h2_split_pair(y1.x, y1.y, p2, q2);
+            h2_split_pair(y1.z, y1.w, p3, q3);
             u32x4 p = {p0, p1, p2, p3}, q = {q0, q1, q2, q3};
             rows16_swap(p);
             rows16_swap(q);

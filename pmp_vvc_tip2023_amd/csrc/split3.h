@@ -60,6 +60,37 @@ __device__ __forceinline__ void split2(float v, _Float16 &a, _Float16 &b)
     b = (_Float16)(v - (float)a);   // v - a is exact in fp32; b keeps its leading 11 bits
 }
 
+// ---- mixed-precision FMA (v_fma_mix_f32 / v_fma_mixlo_f16 / v_fma_mixhi_f16): an fp16 operand enters an fp32 FMA without a
+// conversion instruction and the fp32 result can be written as fp16.  Two uses, both BIT-IDENTICAL to the conversion sequences they
+// replace (the FMA's single rounding acts on an exactly representable value):
+//   value of a split-2 element, (float)h0 + (float)h1:     one instruction instead of two conversions and an add;
+//   second term of a split, h1 = fp16(v - (float)h0):       one instruction instead of a conversion back and a subtraction.
+// hipcc folds fma(x, 1, y) into an add and never emits these instructions by itself, hence the asm.
+__device__ __forceinline__ float h2_sum_lo(unsigned h0, unsigned h1)   // (float)lo16(h0) + (float)lo16(h1)
+{
+    float d;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(h0), "v"(h1));
+    return d;
+}
+__device__ __forceinline__ float h2_sum_hi(unsigned h0, unsigned h1)   // (float)hi16(h0) + (float)hi16(h1)
+{
+    float d;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(h0), "v"(h1));
+    return d;
+}
+// (v, w), both inside the fp16 range -> p = (f16(v), f16(w)) and q = (f16(v - lo(p)), f16(w - hi(p))): 3 instructions for 2 values
+__device__ __forceinline__ void h2_split_pair_noclamp(float v, float w, unsigned &p, unsigned &q)
+{
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p) : "v"(v), "v"(w));
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(q) : "v"(v), "v"(w), "v"(p));
+}
+// the same with the clamp of split2(): values beyond +-65504 saturate (and raise the range flag where the caller tracks it)
+__device__ __forceinline__ void h2_split_pair(float v, float w, unsigned &p, unsigned &q)
+{
+    h2_split_pair_noclamp(__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(w, -65504.f, 65504.f), p, q);
+}
+
 // Saturation tracking (pmp_get_saturation, include/pmp.h): every kernel that writes split-2 planes keeps the largest |value|
 // it stores and raises the context's sticky flag when the clamp above fired for any of them.
 // The maximum is taken on the magnitudes' BIT PATTERNS as unsigned integers: ordered like the floats for finite values and
@@ -78,21 +109,23 @@ __device__ __forceinline__ void sat_report(unsigned *flag, float amax)
     if (flag && sat_bits(amax) > 0x477fe000u) atomicOr(flag, 1u);   // 0x477fe000 = 65504.f; true for NaN as well
 }
 
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ f32x4 load_split2_4(const unsigned short *p, size_t plane_stride)
 {
-    const f16x4 a = *reinterpret_cast<const f16x4 *>(p), b = *reinterpret_cast<const f16x4 *>(p + plane_stride);
-    f32x4 v;
-    v.x = (float)a.x + (float)b.x; v.y = (float)a.y + (float)b.y; v.z = (float)a.z + (float)b.z; v.w = (float)a.w + (float)b.w;
-    return v;
+    const u32x2_t a = *reinterpret_cast<const u32x2_t *>(p), b = *reinterpret_cast<const u32x2_t *>(p + plane_stride);
+    return (f32x4){h2_sum_lo(a.x, b.x), h2_sum_hi(a.x, b.x), h2_sum_lo(a.y, b.y), h2_sum_hi(a.y, b.y)};
 }
 
 __device__ __forceinline__ void store_split2_4(unsigned short *p, size_t plane_stride, f32x4 v)
 {
-    _Float16 a0, a1, a2, a3, b0, b1, b2, b3;
-    split2(v.x, a0, b0); split2(v.y, a1, b1); split2(v.z, a2, b2); split2(v.w, a3, b3);
-    const f16x4 a = {a0, a1, a2, a3}, b = {b0, b1, b2, b3};
-    *reinterpret_cast<f16x4 *>(p) = a;
-    *reinterpret_cast<f16x4 *>(p + plane_stride) = b;
+    u32x2_t a, b;
+    unsigned a0, b0, a1, b1;
+    h2_split_pair(v.x, v.y, a0, b0);
+    h2_split_pair(v.z, v.w, a1, b1);
+    a.x = a0; a.y = a1; b.x = b0; b.y = b1;
+    *reinterpret_cast<u32x2_t *>(p) = a;
+    *reinterpret_cast<u32x2_t *>(p + plane_stride) = b;
 }
 
 // ---- 16-byte epilogue accesses of the split-2 kernels.  An MFMA accumulator leaves lane (xl, g) with the 4 couts 4g.. of one
@@ -120,16 +153,20 @@ __device__ __forceinline__ f32x4 h2_hi4(u32x4 v)
     return (f32x4){(float)h.x, (float)h.y, (float)h.z, (float)h.w};
 }
 
+// values of the 4 channels in (x, y) / (z, w) of a high-term register p and a low-term register q
+__device__ __forceinline__ f32x4 h2_sum4_lo(u32x4 p, u32x4 q) { return (f32x4){h2_sum_lo(p.x, q.x), h2_sum_hi(p.x, q.x), h2_sum_lo(p.y, q.y), h2_sum_hi(p.y, q.y)}; }
+__device__ __forceinline__ f32x4 h2_sum4_hi(u32x4 p, u32x4 q) { return (f32x4){h2_sum_lo(p.z, q.z), h2_sum_hi(p.z, q.z), h2_sum_lo(p.w, q.w), h2_sum_hi(p.w, q.w)}; }
+
 // two rows of one cout group -> their high-term dwords p = (row m: x, y | row m+1: z, w) and low-term dwords q
 __device__ __forceinline__ void split2_rows(f32x4 r0, f32x4 r1, u32x4 &p, u32x4 &q)
 {
-    _Float16 a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3, d0, d1, d2, d3;
-    split2(r0.x, a0, b0); split2(r0.y, a1, b1); split2(r0.z, a2, b2); split2(r0.w, a3, b3);
-    split2(r1.x, c0, d0); split2(r1.y, c1, d1); split2(r1.z, c2, d2); split2(r1.w, c3, d3);
-    const u32x2 pa = __builtin_bit_cast(u32x2, (f16x4){a0, a1, a2, a3}), pc = __builtin_bit_cast(u32x2, (f16x4){c0, c1, c2, c3});
-    const u32x2 qb = __builtin_bit_cast(u32x2, (f16x4){b0, b1, b2, b3}), qd = __builtin_bit_cast(u32x2, (f16x4){d0, d1, d2, d3});
-    p = (u32x4){pa.x, pa.y, pc.x, pc.y};
-    q = (u32x4){qb.x, qb.y, qd.x, qd.y};
+    unsigned p0, q0, p1, q1, p2, q2, p3, q3;
+    h2_split_pair(r0.x, r0.y, p0, q0);
+    h2_split_pair(r0.z, r0.w, p1, q1);
+    h2_split_pair(r1.x, r1.y, p2, q2);
+    h2_split_pair(r1.z, r1.w, p3, q3);
+    p = (u32x4){p0, p1, p2, p3};
+    q = (u32x4){q0, q1, q2, q3};
 }
 
 // same, with the streaming (non-temporal) hint: activations are written once and read by the NEXT launch, far beyond L2
