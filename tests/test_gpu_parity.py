@@ -154,6 +154,30 @@ def test_small_calls_need_small_workspaces():
         e2.close()
 
 
+def test_parked_workspace_is_reused_and_trimmed(g1):
+    """pmp_destroy parks a large activation workspace for the next context on the device (a 10 GB hipMalloc right after a hipFree
+    stalls 0.5-1.4 s now and then on this hardware, profiles/r03_notes.txt); pmp_trim gives it back.  Results do not depend on where
+    the workspace came from, and a context reports what its passes NEED, not the size of a buffer it took over."""
+    from pmp_vvc_tip2023_amd import engine
+    y = np.concatenate([g1["block_y"]] * 8)                  # 128 luma blocks: 320 MB of workspace, above the parking threshold
+    outs, need = [], []
+    for k in range(3):
+        e2 = engine.Engine(0, allow_synthetic_mtt=True)
+        try:
+            outs.append(e2.inference_pre_QBD("Luma", 22, y if k != 1 else y[:64]))
+            need.append(e2.workspace_bytes())
+        finally:
+            e2.close()
+        if k == 1:
+            assert e2.lib.pmp_trim() == 0                    # the third context allocates afresh
+    assert need[0] == need[2] and 0 < need[1] < need[0]      # the second context ran in the first one's (larger) buffer
+    for a, b in zip(outs[0], outs[2]):
+        assert np.array_equal(a, b)
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a[:64], b)
+    assert e2.lib.pmp_trim() == 0
+
+
 def test_default_chunk_boundary(eng):
     """More blocks than one library pass (default chunk 4096): the ragged second pass gives what a call on those blocks alone gives."""
     from pmp_vvc_tip2023_amd import synth
@@ -339,6 +363,49 @@ def test_device_calls_do_not_stall_the_host_and_the_guard_still_repairs(g1, orac
         assert ei.value.code == -7
         e2.synchronize()                                      # the context is usable again
     finally:
+        e2.close()
+
+
+def test_winograd_form_of_the_trunk_convolutions(g1, oracle_lib):
+    """conv_f16x3_wx.hip (opt-in, pmp_debug_set_winograd): the 3x3 64->64 convolutions with a Winograd F(2,3) transform along x - 1.5x fewer
+    MFMAs, not bit-identical to the direct form but inside the same tolerance: logits within 1e-3 of the oracle for both components, split
+    flags bit-exact on the device logits, and the range guard still repairs a saturating net (a V beyond the fp16 range turns into NaN
+    outputs, which the NaN-aware flag catches)."""
+    from oracle import nets_torch as O
+    from pmp_vvc_tip2023_amd import engine, synth, weights as W
+    y, u, v = synth.recipe_r_blocks(40, 321)
+    e2 = engine.Engine(0, allow_synthetic_mtt=True)
+    try:
+        e2.set_precision("f16x3")
+        for comp in ("Luma", "Chroma"):
+            luma = comp == "Luma"
+            wq, _ = W.load_net_weights(comp + "_Q", 27)
+            wb, _ = W.load_net_weights(comp + "_MSBD", 27, allow_synthetic=True)
+            x = O.luma_input(y) if luma else O.chroma_input(y, u, v)
+            oq, obt, od = O.infer_qbd(wq, wb, x, luma)
+            e2._ck(e2.lib.pmp_debug_set_winograd(e2.h, 0))
+            direct = e2.infer_postprocess(comp, 27, y, u, v, want_logits=True)
+            e2._ck(e2.lib.pmp_debug_set_winograd(e2.h, 1))
+            hor, ver, q8, d8, qt, bt, dire = e2.infer_postprocess(comp, 27, y, u, v, want_logits=True)
+            err = max(np.abs(qt - oq).max(), np.abs(bt - obt).max(), np.abs(dire - od).max())
+            assert err < TOL, "%s logits off by %g in the Winograd form" % (comp, err)
+            assert not np.array_equal(bt, direct[5])              # it really is another kernel ...
+            assert np.abs(bt - direct[5]).max() < 2e-4            # ... with the same answer
+            oh, ov, oq8, od8 = oracle_lib.seq_post_process(qt, bt, dire, comp, 1, 64 * 40, 64, None)
+            assert np.array_equal(hor, oh) and np.array_equal(ver, ov) and np.array_equal(q8, oq8.astype(np.uint8)) and np.array_equal(d8, od8)
+            assert not e2.saturated()
+        # range guard through the Winograd kernels
+        yb = np.ascontiguousarray(g1["block_y"][:6])
+        w = _range_stress_weights()
+        wq, _ = W.load_net_weights("Luma_Q", 22)
+        oq, obt, od = O.infer_qbd(wq, w, O.luma_input(yb), True)
+        e2.load("Luma", 22)
+        e2.load_pretrain_model("Luma_MSBD", 22, w)
+        qt, bt, dire = e2.inference_pre_QBD("Luma", 22, yb)
+        assert e2.saturated() and e2.saturation_reruns() == 1
+        assert max(np.abs(qt - oq).max(), np.abs(bt - obt).max(), np.abs(dire - od).max()) < TOL
+    finally:
+        e2._ck(e2.lib.pmp_debug_set_winograd(e2.h, 0))
         e2.close()
 
 

@@ -129,3 +129,57 @@ def test_bench_self_launch_propagates_rank_failure():
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0 and not r.stdout.strip()
     assert r.stderr.count("no CPU fallback") == 2          # both ranks were started and both refused
+
+
+def test_spawn_ranks_stops_everyone_when_one_rank_dies(tmp_path):
+    """a rank other than 0 that dies first must end the job at once - rank 0 would otherwise sit in its first
+    collective until the timeout.  spawn_ranks polls ALL children: here rank 1 exits with code 7 immediately while rank 0 sleeps
+    for ten minutes; the call returns 7 within seconds and rank 0 is gone (killed by PID)."""
+    import time
+    script = tmp_path / "w.py"
+    pidfile = tmp_path / "pid0"
+    script.write_text(textwrap.dedent('''
+        import os, sys, time
+        if os.environ["RANK"] == "1":
+            sys.exit(7)
+        open(%r, "w").write(str(os.getpid()))
+        print("rank 0 line", flush=True)
+        time.sleep(600)
+    ''' % str(pidfile)))
+    t0 = time.time()
+    rc, out = parallel.spawn_ranks([sys.executable, str(script)], 2, capture_rank0=True)
+    assert rc == 7 and time.time() - t0 < 30
+    assert out is not None and b"rank 0 line" in out
+    pid = int(pidfile.read_text())
+    time.sleep(0.2)
+    with pytest.raises(ProcessLookupError):
+        os.kill(pid, 0)
+    # all ranks fine -> 0, rank 0's stdout relayed whole
+    ok = tmp_path / "ok.py"
+    ok.write_text("import os\nprint('r' + os.environ['RANK'] + ' of ' + os.environ['WORLD_SIZE'] + ' ' + os.environ['MASTER_ADDR'])\n")
+    rc, out = parallel.spawn_ranks([sys.executable, str(ok)], 3, capture_rank0=True)
+    assert rc == 0 and out.strip() == b"r0 of 3 127.0.0.1"
+
+
+WORKER_P = textwrap.dedent('''
+    import os, sys
+    sys.path.insert(0, %(root)r)
+    from pmp_vvc_tip2023_amd import parallel
+    import numpy as np
+    rank, world, _ = parallel.init_process_group(None, timeout_s=60)
+    info = parallel.preflight(None)
+    assert info["ranks"] == world == 2 and info["backend"] == "gloo" and info["ms"] > 0, info
+    tot = parallel.all_reduce_sum(np.arange(12, dtype=np.int64).reshape(2, 6) * (rank + 1))
+    assert np.array_equal(tot, np.arange(12).reshape(2, 6) * 3), tot
+    import torch.distributed as dist
+    dist.barrier(); dist.destroy_process_group()
+''')
+
+
+def test_preflight_and_size_table_reduce_over_gloo(tmp_path):
+    """The first collective of every multi-rank job (parallel.preflight: verified gather + all-reduce) and the int64 table reduce of
+    the sharded emission, world 2 over gloo."""
+    script = tmp_path / "worker_p.py"
+    script.write_text(WORKER_P % {"root": ROOT})
+    rc, _ = parallel.spawn_ranks([sys.executable, str(script)], 2, env_extra={"OMP_NUM_THREADS": "1"})
+    assert rc == 0
