@@ -137,6 +137,8 @@ static int infer_passes(pmp_ctx *c, bool luma, NetWeights &wq, NetWeights &wb, c
 {
     int rc0;     // weights are packed per datapath, on first use (the load packed the datapath that was current then)
     if ((rc0 = ensure_datapath(c, wq, c->precision)) != PMP_OK || (rc0 = ensure_datapath(c, wb, c->precision)) != PMP_OK) return rc0;
+    if (c->winograd && c->precision == PMP_PRECISION_F16X3 &&
+        ((rc0 = ensure_datapath(c, wq, 3)) != PMP_OK || (rc0 = ensure_datapath(c, wb, 3)) != PMP_OK)) return rc0;     // Winograd-x streams
     for (int64_t o = 0; o < n; o += c->chunk) {
         const int m = (int)((n - o) < c->chunk ? (n - o) : c->chunk);
         const uint8_t *y = by + o * 68 * 68;

@@ -28,29 +28,38 @@ struct Blob {
 
 int roundup16(int v) { return (v + 15) & ~15; }
 
+// One device allocation and one host-to-device copy per build_net call: upload() only stages the bytes and remembers where the device
+// pointer has to be written; finalize() allocates, copies and patches.  (250 hipMalloc + hipMemcpy pairs per MTT net were a third of
+// the load time.)  The patched fields must have stable addresses until finalize(): NetWeights members and std::map values do.
 struct Uploader {
     pmp_ctx *c;
     NetWeights *nw;
-    int upload(const std::vector<float> &h, float **out)
+    std::vector<char> stage;
+    std::vector<std::pair<void **, size_t>> fixups;
+    int put(const void *src, size_t bytes, void **out)
     {
-        void *d = nullptr;
-        hipError_t e = hipMalloc(&d, h.size() * sizeof(float));
-        if (e != hipSuccess) return hip_fail(c, e, "hipMalloc(weights)");
-        e = hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
-        if (e != hipSuccess) { hipFree(d); return hip_fail(c, e, "hipMemcpy(weights)"); }
-        nw->allocs.push_back(d);
-        *out = static_cast<float *>(d);
+        const size_t off = (stage.size() + 255) & ~(size_t)255;
+        stage.resize(off + bytes);
+        if (bytes) std::memcpy(stage.data() + off, src, bytes);
+        fixups.emplace_back(out, off);
+        *out = reinterpret_cast<void *>(~(uintptr_t)0);     // "pending": non-null, so that nothing is staged twice; patched by finalize()
         return PMP_OK;
     }
-    int upload16(const std::vector<unsigned short> &h, unsigned short **out)
+    int upload(const std::vector<float> &h, float **out) { return put(h.data(), h.size() * sizeof(float), reinterpret_cast<void **>(out)); }
+    int upload16(const std::vector<unsigned short> &h, unsigned short **out) { return put(h.data(), h.size() * sizeof(unsigned short), reinterpret_cast<void **>(out)); }
+    void abandon() { for (auto &f : fixups) *f.first = nullptr; fixups.clear(); stage.clear(); }
+    int finalize()
     {
+        if (fixups.empty()) return PMP_OK;
         void *d = nullptr;
-        hipError_t e = hipMalloc(&d, h.size() * sizeof(unsigned short));
-        if (e != hipSuccess) return hip_fail(c, e, "hipMalloc(weights)");
-        e = hipMemcpy(d, h.data(), h.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
-        if (e != hipSuccess) { hipFree(d); return hip_fail(c, e, "hipMemcpy(weights)"); }
+        hipError_t e = hipMalloc(&d, stage.size() ? stage.size() : 256);
+        if (e != hipSuccess) { abandon(); return hip_fail(c, e, "hipMalloc(weights)"); }
+        e = hipMemcpy(d, stage.data(), stage.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { hipFree(d); abandon(); return hip_fail(c, e, "hipMemcpy(weights)"); }
+        for (auto &f : fixups) *f.first = static_cast<char *>(d) + f.second;
         nw->allocs.push_back(d);
-        *out = static_cast<unsigned short *>(d);
+        fixups.clear();
+        stage.clear();
         return PMP_OK;
     }
 };
@@ -75,8 +84,7 @@ int need(pmp_ctx *c, const Blob &b, const std::string &name, std::initializer_li
 // missing formats are added (ensure_datapath).
 int load_rb(pmp_ctx *c, const Blob &b, Uploader &up, const std::string &name, int cin, int cout, int k, bool direct, unsigned mask)
 {
-    auto it = up.nw->rb.find(name);
-    RBWeights r = it != up.nw->rb.end() ? it->second : RBWeights();
+    RBWeights &r = up.nw->rb[name];       // a map value: its address is stable, the uploader patches its pointers at the end
     r.cin = cin; r.cout = cout; r.k = k; r.direct = direct; r.has_sc = cin != cout;
     r.cin_pad = roundup16(cin); r.cout_pad = roundup16(cout);
     const float *w0, *w2, *wsc = nullptr;
@@ -109,13 +117,12 @@ int load_rb(pmp_ctx *c, const Blob &b, Uploader &up, const std::string &name, in
             if ((rc = up.upload16(pack_h2(w0, cout, cin, k, k, r.cout_pad, r.cin_pad, r.k0), &r.w0h))) return rc;
             if ((rc = up.upload16(pack_h2(w2, cout, cout, k, k, r.cout_pad, r.cout_pad, r.k2), &r.w2h))) return rc;
             if (wsc && (rc = up.upload16(pack_h2(wsc, cout, cin, 1, 1, r.cout_pad, r.cin_pad, r.k2), &r.wsch))) return rc;
-            if (k == 3 && cin == 64 && cout == 64) {     // the trunk blocks: Winograd-x form of both convolutions
-                if ((rc = up.upload16(pack_h2_wx(w0, &r.k0w), &r.w0w))) return rc;
-                if ((rc = up.upload16(pack_h2_wx(w2, &r.k2w), &r.w2w))) return rc;
-            }
+        }
+        if ((mask & (1u << 3)) && k == 3 && cin == 64 && cout == 64 && !r.w0w) {     // pseudo-datapath 3: the Winograd-x form of the trunk blocks (opt-in)
+            if ((rc = up.upload16(pack_h2_wx(w0, &r.k0w), &r.w0w))) return rc;
+            if ((rc = up.upload16(pack_h2_wx(w2, &r.k2w), &r.w2w))) return rc;
         }
     }
-    up.nw->rb[name] = r;
     return PMP_OK;
 }
 
@@ -146,7 +153,7 @@ static int build_net(pmp_ctx *c, int net_id, const Blob &b, NetWeights &nw, unsi
     Uploader up{c, &nw};
     int rc = PMP_OK;
     const bool want_h2 = mask & (1u << PMP_PRECISION_F16X3);
-    auto fail = [&](int code) { return code; };
+    auto fail = [&](int code) { up.abandon(); return code; };
 
     if (!msbd) {
         // Model_QBD.py:60-76 (luma) / :158-174 (chroma)
@@ -224,6 +231,7 @@ static int build_net(pmp_ctx *c, int net_id, const Blob &b, NetWeights &nw, unsi
         if ((rc = load_head(c, b, up, "conv_B2", 2, 1))) return fail(rc);
         if ((rc = load_head(c, b, up, "conv_B3", 2, 2))) return fail(rc);
     }
+    if ((rc = up.finalize()) != PMP_OK) return rc;
     nw.packed |= mask;
     return PMP_OK;
 }
@@ -257,7 +265,7 @@ int load_net_weights(pmp_ctx *c, int net_id, int qp, const float *blob, const pm
     }
     for (int i = 0; i < ndesc; ++i) nw.descs[i].name = nw.names[i].c_str();
     Blob b{nw.host.data(), nw.descs.data(), ndesc};
-    const int rc = build_net(c, net_id, b, nw, 1u << c->precision);
+    const int rc = build_net(c, net_id, b, nw, (1u << c->precision) | (c->winograd ? 1u << 3 : 0u));
     if (rc != PMP_OK) { free_net_weights(nw); return rc; }
     nw.loaded = true;
     const int key = net_id * 100 + qp;
