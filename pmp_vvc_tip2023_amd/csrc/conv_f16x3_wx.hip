@@ -18,6 +18,7 @@
 // {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... (MI355X_MICROARCH.md, LDS): with lane = (pair | row << 3) + 16 (half | tap << 1) the
 // 16 lanes of a group hit 16 different 16-byte slots of the 256-byte bank window when the row stride is a multiple of 256 B.
 #include <cstdio>
+#include <vector>
 
 #include "pmp_kernels.h"
 #include "split3.h"
@@ -99,6 +100,16 @@ __device__ __forceinline__ void wx_transform_store(unsigned it_lds, const u32x4 
 __device__ __forceinline__ void wx_mfma(f32x4 &c, const f16x8 &a, const f16x8 &b)
 {
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+
+// diagnostic build (ABL & 128): shader-clock stamps of wave 0 at phase boundaries
+__device__ __forceinline__ unsigned long long wx_stamp()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
 }
 
 // one 16-byte piece per lane from global memory straight into LDS (no registers): LDS address = m0 + 16 * lane
@@ -237,44 +248,58 @@ __global__ __launch_bounds__(256, 2) void conv_h2_wx_kernel(ConvX6Args a)
     if ((ABL & 32) && blockIdx.x >= 256 && blockIdx.x < 512) {      // A/B: the second workgroup of every CU starts half a tile late
         for (int i = 0; i < 90; ++i) __builtin_amdgcn_s_sleep(127);
     }
+    unsigned long long ts[12];
+    int nts = 0;
+    auto stamp = [&]() __attribute__((always_inline)) { if (ABL & 128) ts[nts++] = wx_stamp(); };
+    stamp();                                        // 0: start
     stage_load(0);
     dma_B(0);
     dma_B(1);
     wload(0);
     stage_store(0);
+    stamp();                                        // 1: group 0 loaded and transformed
     dma_done();
     if (!(ABL & 16)) __syncthreads();               // raw rows of groups 0, 1 are in LDS
     stage_load(1);
     transform_B(0);
     if (!(ABL & 16)) __syncthreads();               // V(0) complete
+    stamp();                                        // 2: prologue done
     // K0: even group 0 (buffer 0)
     kstep(0, 0, 0, nothing);
+    stamp();                                        // 3: K0
     stage_store(1);
     transform_B(1);
     stage_load(2);
     if (!(ABL & 16)) __syncthreads();               // V(1) complete; every wave is done with RAW[1]
+    stamp();                                        // 4: staging of group 1 + barrier
     // K1: the cross step of pair 0 reads both buffers
     dma_B(2);
     dma_B(3);
     kstep(1, 1, 1, nothing);
+    stamp();                                        // 5: K1
     dma_done();
     if (!(ABL & 16)) __syncthreads();               // every wave is done with buffer 0; raw rows of groups 2, 3 are in LDS
+    stamp();                                        // 6: DMA wait + barrier
     // K2: odd group 1 (buffer 1).  Buffer 0 is free from here on: group 2 goes in FIRST (its pixels were requested before K1), so
     // that group 3's can be requested two K-steps before they are needed
     stage_store(2);
     transform_B(2);
     stage_load(3);
+    stamp();                                        // 7: staging of group 2
     kstep(2, 0, 1, nothing);
     if (!(ABL & 16)) __syncthreads();               // V(2) complete, buffer 1 free
     // K3: even group 2 (buffer 0)
     kstep(3, 0, 0, nothing);
+    stamp();                                        // 8: K2 + barrier + K3
     stage_store(3);
     transform_B(3);
     res_prefetch();                                 // the staging registers are free now: half of the residual tile, two K-steps ahead
     if (!(ABL & 16)) __syncthreads();
+    stamp();                                        // 9: staging of group 3 + barrier
     // K4, K5: cross step of pair 1, odd group 3
     kstep(4, 1, 1, nothing);
     kstep(5, 0, 1, nothing);
+    stamp();                                        // 10: K4 + K5
 
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");     // the last MFMA results must have landed before a VALU instruction reads them
     // ---- epilogue: output transform, 1/S, residual, ReLU, split, store
@@ -334,6 +359,11 @@ __global__ __launch_bounds__(256, 2) void conv_h2_wx_kernel(ConvX6Args a)
         }
     }
     sat_report(a.sat, omax);
+    if ((ABL & 128) && a.dbg && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // include the store acknowledgements in the epilogue span
+        ts[nts++] = wx_stamp();                             // 11: epilogue done
+        for (int i = 0; i < 12; ++i) a.dbg[(size_t)blockIdx.x * 12 + i] = ts[i];
+    }
 }
 
 bool conv_h2_wx_applicable(const ConvX6Args &a)
@@ -352,6 +382,29 @@ hipError_t launch_conv_h2_wx(hipStream_t s, const ConvX6Args &a_in)
     { static bool once = false; if (!once) { once = true; int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_h2_wx_kernel<0>, 256, 0);
       hipFuncAttributes fa; hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(conv_h2_wx_kernel<0>));
       fprintf(stderr, "conv_h2_wx_kernel: occupancy API says %d workgroups per CU; %d VGPRs, %zu B LDS\n", nb, fa.numRegs, fa.sharedSizeBytes); } }
+    if (g_conv_variant == 200 + 128) {       // stamp report
+        unsigned long long *ddbg = nullptr;
+        if (hipMalloc((void **)&ddbg, (size_t)grid * 12 * 8) != hipSuccess) return hipErrorOutOfMemory;
+        hipMemsetAsync(ddbg, 0, (size_t)grid * 12 * 8, s);
+        a.dbg = ddbg;
+        hipLaunchKernelGGL(conv_h2_wx_kernel<128>, dim3(grid), dim3(256), 0, s, a);
+        hipStreamSynchronize(s);
+        static int reported = 0;
+        if (reported++ == 2) {
+            std::vector<unsigned long long> hd((size_t)grid * 12);
+            hipMemcpy(hd.data(), ddbg, hd.size() * 8, hipMemcpyDeviceToHost);
+            double d[11] = {0};
+            for (int i = 0; i < grid; ++i) for (int k = 0; k < 11; ++k) d[k] += (double)(hd[(size_t)i * 12 + k + 1] - hd[(size_t)i * 12 + k]);
+            const char *nm[11] = {"load+transform group 0", "DMA wait, barrier, B(0), barrier", "K0", "staging group 1 + barrier", "K1 (cross)", "DMA wait + barrier",
+                                  "staging group 2", "K2 + barrier + K3", "staging group 3 + barrier", "K4 + K5", "epilogue incl. store ack"};
+            double tot = 0;
+            for (int k = 0; k < 11; ++k) tot += d[k] / grid;
+            fprintf(stderr, "winograd-x stamps (mean ticks of wave 0 per workgroup; %d workgroups, total %.0f):\n", grid, tot);
+            for (int k = 0; k < 11; ++k) fprintf(stderr, "   %-36s %8.0f  (%4.1f %%)\n", nm[k], d[k] / grid, 100.0 * d[k] / grid / tot);
+        }
+        hipFree(ddbg);
+        return hipGetLastError();
+    }
     switch (g_conv_variant >= 200 ? g_conv_variant - 200 : 0) {
     case 1: hipLaunchKernelGGL(conv_h2_wx_kernel<1>, dim3(grid), dim3(256), 0, s, a); return hipGetLastError();
     case 2: hipLaunchKernelGGL(conv_h2_wx_kernel<2>, dim3(grid), dim3(256), 0, s, a); return hipGetLastError();
