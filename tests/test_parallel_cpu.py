@@ -141,11 +141,15 @@ def test_spawn_ranks_stops_everyone_when_one_rank_dies(tmp_path):
     script.write_text(textwrap.dedent('''
         import os, sys, time
         if os.environ["RANK"] == "1":
+            while not os.path.exists(%r):          # die only once rank 0 is up and has said its line
+                time.sleep(0.02)
             sys.exit(7)
-        open(%r, "w").write(str(os.getpid()))
         print("rank 0 line", flush=True)
+        with open(%r + ".tmp", "w") as f:
+            f.write(str(os.getpid()))
+        os.rename(%r + ".tmp", %r)
         time.sleep(600)
-    ''' % str(pidfile)))
+    ''' % (str(pidfile), str(pidfile), str(pidfile), str(pidfile))))
     t0 = time.time()
     rc, out = parallel.spawn_ranks([sys.executable, str(script)], 2, capture_rank0=True)
     assert rc == 7 and time.time() - t0 < 30
