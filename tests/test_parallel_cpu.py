@@ -128,7 +128,8 @@ def test_bench_self_launch_propagates_rank_failure():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0 and not r.stdout.strip()
-    assert r.stderr.count("no CPU fallback") == 2          # both ranks were started and both refused
+    # every rank refuses; the launcher stops the others as soon as the first one has (it may be gone before it could say so)
+    assert 1 <= r.stderr.count("no CPU fallback") <= 2 and "stopping the other ranks" in r.stderr
 
 
 def test_spawn_ranks_stops_everyone_when_one_rank_dies(tmp_path):
