@@ -218,6 +218,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_wx_kernel(ConvX6Args a)
                     na = *reinterpret_cast<const f16x8 *>(vb + np * 256 + nrp * 2 * WX_ROWB);
                     nb = *reinterpret_cast<const f16x8 *>(vb + np * 256 + nrp * 2 * WX_ROWB + WX_PLANEB);
                 }
+                asm volatile("s_nop 1");      // should hipcc ever copy a fragment with a VALU move right here: the two wait states an MFMA source needs
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) wx_mfma(acc[p][rp][nt], wbuf[blk & 1][1][nt], xa);
 #pragma unroll
