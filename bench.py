@@ -346,6 +346,18 @@ def main():
                 "peak_basis": PEAK_NOTE[args.precision],
                 "launches": launches, "avg_launch_ms": round(ms / launches, 4),
                 "flop_per_launch": flops / launches}
+        # The same launches against the OTHER roof.  A 3x3 64->64 layer moves, per output pixel, 64 channels in + 64 out + (every second
+        # launch: the residual block's second convolution) 64 residual, at ACT_BYTES per element in this datapath's activation format;
+        # 73 728 FLOP per pixel.  On the f16x3 path the two fractions are about equal: the class sits on the ridge of both roofs.
+        act_bytes = {"f16x3": 4, "bf16x6": 6, "fp32": 4}[args.precision]
+        alg_bytes = flops / launches / 73728.0 * 64 * act_bytes * 2.5
+        t_launch = ms / launches * 1e-3
+        roof["hbm_view"] = {"algorithmic_bytes_per_launch": round(alg_bytes), "achieved": round(alg_bytes / t_launch / 1e9, 1),
+                            "traffic_rate": round(traffic / t_launch / 1e9, 1) if traffic else None, "peak": 8000, "unit": "GB/s",
+                            "frac": round(alg_bytes / t_launch / 8e12, 4), "copy_bandwidth_measured": 5110,
+                            "note": "bytes = pixels x 64 channels x %d B x (in + out + residual on every second launch); the PMC traffic is lower "
+                                    "than that where the residual still sits in L2 / MALL; a device-to-device copy sustains 5110 GB/s on "
+                                    "this pool (tools/hbm_probe.py, profiles/r03_notes.txt section 3)" % act_bytes}
 
     if args.breakdown and rank == 0:
         eng.ktime_enable(0xFFFF)
