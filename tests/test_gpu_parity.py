@@ -778,6 +778,9 @@ def test_bench_json_contract(tmp_path):
     assert d["parity"]["logit_max_abs_err"] < 1e-3 and d["parity"]["flag_mismatch_vs_oracle_postproc_of_device_logits"] == 0
     assert d["value"] > 50 * cb["value"]   # sanity: the GPU path is not the CPU path
     assert rf["traffic_source"] is None or "pmc_traffic.json" in rf["traffic_source"]
+    hv = rf["hbm_view"]                         # the same launches against the HBM roof: algorithmic bytes / measured launch time
+    assert hv["unit"] == "GB/s" and hv["peak"] == 8000 and 0 < hv["frac"] < 1 and abs(hv["frac"] - hv["achieved"] / hv["peak"]) < 1e-3
+    assert abs(hv["algorithmic_bytes_per_launch"] - rf["flop_per_launch"] / 73728.0 * 640) < 2
     e2e = d["e2e_host_buffers"]                 # the H2D/D2H-inclusive figure beside the device-resident one
     assert e2e["unit"] == "CTU/s" and 0 < e2e["value"] <= d["value"] * 1.5 and e2e["h2d_bytes_per_step"] == 64 * 68 * 68
     assert set(d["extra"]["luma_ctu_per_s_by_qp"]) == {"22", "27", "32", "37"} and d["extra"]["chroma_qp22_ctu_per_s"] > 0
