@@ -227,9 +227,11 @@ int pmp_ktime_get(pmp_ctx *ctx, int cls, int64_t *launches, double *ms, double *
  *      in-process A/B timing (tools/conv_ab.py, tools/variants_agree.py; the list is in conv_f16x3.hip, the numbers in DESIGN.md 4.1a). ---- */
 int pmp_debug_set_conv_variant(int variant);
 
-/* ---- experiment switch (f16x3 datapath): run the 3x3 64->64 convolutions - 55 % of the luma step - in the Winograd F(2,3)-along-x
- *      form (conv_f16x3_wx.hip: 1.5x fewer MFMAs, fp32-equivalent logits, tools/precision_winograd.py).  Off by default until it wins
- *      its A/B; results are within the 1e-3 tolerance either way, not bit-identical to the direct form. ---- */
+/* ---- measurement hook (f16x3 datapath): run the 3x3 64->64 convolutions - 55 % of the luma step - in the Winograd F(2,3)-along-x
+ *      form (conv_f16x3_wx.hip: 1.5x fewer MFMAs, fp32-equivalent logits within the 1e-3 tolerance, not bit-identical to the direct
+ *      form).  It did not beat the direct kernels (profiles/r03_notes.txt), so like the other forms that lost their
+ *      A/B it exists in the measurement library libpmp_hip_abl.so only (`make abl`; tools/wx_probe.py, tools/wx_ablate.py): the
+ *      product library accepts on = 0 and answers PMP_E_INVALID to anything else. ---- */
 int pmp_debug_set_winograd(pmp_ctx *ctx, int on);
 
 /* ---- test hook (host only, no GPU needed): the f16x3 weight packing of one OIHW conv tensor (conv_f16x3.hip).

@@ -858,8 +858,8 @@ hipError_t launch_conv_h2(hipStream_t s, const ConvX6Args &a_in)
         return hipErrorInvalidValue;
     if (a.pool && a.gate) return hipErrorInvalidValue;
     if (!(a.out_scale > 0.f)) return hipErrorInvalidValue;
-    if (conv_h2_wx_applicable(a)) return launch_conv_h2_wx(s, a);     // Winograd-x form of the 3x3 64->64 blocks (the caller set w_wx)
 #ifdef PMP_ABLATION
+    if (conv_h2_wx_applicable(a)) return launch_conv_h2_wx(s, a);     // Winograd-x form of the 3x3 64->64 blocks (the caller set w_wx)
     if ((g_conv_variant == 9 || (g_conv_variant >= 90 && g_conv_variant < 200)) && conv_h2_t32_applicable(a)) return launch_conv_h2_t32(s, a);   // 32x16 tiles, LDS-DMA (A/B: opt-in)
 #endif
     if (a.KH == 3 && a.KW == 3) return launch_h2<3, 3>(s, a);

@@ -161,6 +161,7 @@ std::vector<unsigned short> pack_h2(const float *w, int cout, int cin, int kh, i
     return out;
 }
 
+#ifdef PMP_ABLATION   // measurement library only, with the kernel it feeds
 // Winograd F(2, 3) along x for a 3x3 64 -> 64 convolution (conv_f16x3_wx.hip).  U_p[ky] = sum_kx G[p][kx] w[ky][kx] in fp64, scaled by
 // S = 2^k (max |S U| in [4096, 8192)), two fp16 terms.  Stream [pair P 2][step s 3][position p 4][split 2][cout group 4][64 lanes][8]:
 // a K-step is 16 channels x two vertical taps -  s = 0: (ky0, ky1) of group 2P;  s = 1: ky2 of group 2P and ky2 of group 2P + 1;
@@ -199,6 +200,7 @@ std::vector<unsigned short> pack_h2_wx(const float *w, int *scale_exp)
         }
     return out;
 }
+#endif
 
 // Stem weights for the MFMA stem (conv_misc.hip: stem_mfma_kernel): ONE k1 x k1 convolution with 32 outputs, top-left
 // anchored (the smaller kernels of the MTT stems are zero-padded into it).  w32: [32][cin][k1][k1].  K is ordered

@@ -137,8 +137,10 @@ static int infer_passes(pmp_ctx *c, bool luma, NetWeights &wq, NetWeights &wb, c
 {
     int rc0;     // weights are packed per datapath, on first use (the load packed the datapath that was current then)
     if ((rc0 = ensure_datapath(c, wq, c->precision)) != PMP_OK || (rc0 = ensure_datapath(c, wb, c->precision)) != PMP_OK) return rc0;
+#ifdef PMP_ABLATION
     if (c->winograd && c->precision == PMP_PRECISION_F16X3 &&
         ((rc0 = ensure_datapath(c, wq, 3)) != PMP_OK || (rc0 = ensure_datapath(c, wb, 3)) != PMP_OK)) return rc0;     // Winograd-x streams
+#endif
     for (int64_t o = 0; o < n; o += c->chunk) {
         const int m = (int)((n - o) < c->chunk ? (n - o) : c->chunk);
         const uint8_t *y = by + o * 68 * 68;
@@ -703,8 +705,13 @@ int pmp_debug_set_winograd(pmp_ctx *c, int on)
     CHECK_CTX(c);
     const int rc = settle(c);
     if (rc != PMP_OK) return rc;
+#ifdef PMP_ABLATION
     c->winograd = on ? 1 : 0;
     return PMP_OK;
+#else       // the Winograd-x kernel did not beat the direct form (profiles/r03_notes.txt): it lives in libpmp_hip_abl.so (make abl)
+    if (on) return set_err(c, PMP_E_INVALID, "pmp_debug_set_winograd: the Winograd-x form is built into libpmp_hip_abl.so only (make abl)");
+    return PMP_OK;
+#endif
 }
 
 int pmp_debug_conv_bench(pmp_ctx *c, int n, int h, int w, int cin, int cout, int k, int iters, double *ms_f32, double *ms_x6,
@@ -724,10 +731,13 @@ int pmp_debug_conv_bench(pmp_ctx *c, int n, int h, int w, int cin, int cout, int
     const bool h2 = c->precision == PMP_PRECISION_F16X3;   // the split leg follows the context's datapath
     const int kexp = h2_scale_exp(hw.data(), hw.size());
     std::vector<unsigned short> wx = h2 ? pack_h2(hw.data(), cout, cin, k, k, cout, cin, kexp) : pack_x6(hw.data(), cout, cin, k, k, cout, cin);
-    const bool wino = h2 && c->winograd && k == 3 && cin == 64 && cout == 64;     // the Winograd-x form of this layer (conv_f16x3_wx.hip)
+    bool wino = false;
     int kexp_w = 0;
     std::vector<unsigned short> ww;
+#ifdef PMP_ABLATION
+    wino = h2 && c->winograd && k == 3 && cin == 64 && cout == 64;     // the Winograd-x form of this layer (conv_f16x3_wx.hip)
     if (wino) ww = pack_h2_wx(hw.data(), &kexp_w);
+#endif
     unsigned short *dww = nullptr;
     float *dx = nullptr, *dy = nullptr, *dy2 = nullptr, *dwp = nullptr;
     unsigned short *dxs = nullptr, *dys = nullptr, *dwx = nullptr;

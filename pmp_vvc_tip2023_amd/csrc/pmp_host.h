@@ -119,7 +119,7 @@ struct pmp_ctx {
     unsigned *h_sat = nullptr;             // PMP_SAT_SLOTS pinned host words: flag snapshots of the calls still in flight
     uint64_t sat_seq = 0;
     std::deque<pmp::PendingCall> pending;  // calls whose flag has not been looked at yet (+ the post-processing calls after them)
-    int winograd = 0;                      // f16x3: run the 3x3 64->64 convolutions in the Winograd-x form (pmp_debug_set_winograd)
+    int winograd = 0;                      // measurement library: run the 3x3 64->64 convolutions in the Winograd-x form (pmp_debug_set_winograd); always 0 in the product
     int sat_policy = PMP_SAT_RERUN;
     int sat_seen = 0;                      // sticky: some inference call since pmp_clear_saturation saturated
     int64_t sat_reruns = 0;                // calls re-run on the bf16x6 datapath

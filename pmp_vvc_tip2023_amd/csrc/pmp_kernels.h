@@ -60,9 +60,11 @@ hipError_t launch_conv_h2(hipStream_t s, const ConvX6Args &a);
 bool conv_h2_t32_applicable(const ConvX6Args &a);
 hipError_t launch_conv_h2_t32(hipStream_t s, const ConvX6Args &a);
 #endif
-// conv_f16x3_wx.hip: the 3x3 64->64 convolution with a 1-D Winograd F(2,3) transform along x (1.5x fewer MFMAs)
+#ifdef PMP_ABLATION
+// conv_f16x3_wx.hip (measurement library only): the 3x3 64->64 convolution with a 1-D Winograd F(2,3) transform along x (1.5x fewer MFMAs)
 bool conv_h2_wx_applicable(const ConvX6Args &a);
 hipError_t launch_conv_h2_wx(hipStream_t s, const ConvX6Args &a);
+#endif
 hipError_t launch_f32_to_split2(hipStream_t s, const float *x, unsigned short *out, size_t n, size_t plane_stride, unsigned *sat = nullptr);
 hipError_t launch_split2_to_f32(hipStream_t s, const unsigned short *x, float *out, size_t n, size_t plane_stride);
 

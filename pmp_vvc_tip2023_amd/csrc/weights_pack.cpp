@@ -118,10 +118,12 @@ int load_rb(pmp_ctx *c, const Blob &b, Uploader &up, const std::string &name, in
             if ((rc = up.upload16(pack_h2(w2, cout, cout, k, k, r.cout_pad, r.cout_pad, r.k2), &r.w2h))) return rc;
             if (wsc && (rc = up.upload16(pack_h2(wsc, cout, cin, 1, 1, r.cout_pad, r.cin_pad, r.k2), &r.wsch))) return rc;
         }
-        if ((mask & (1u << 3)) && k == 3 && cin == 64 && cout == 64 && !r.w0w) {     // pseudo-datapath 3: the Winograd-x form of the trunk blocks (opt-in)
+#ifdef PMP_ABLATION
+        if ((mask & (1u << 3)) && k == 3 && cin == 64 && cout == 64 && !r.w0w) {     // pseudo-datapath 3: the Winograd-x form of the trunk blocks (measurement library)
             if ((rc = up.upload16(pack_h2_wx(w0, &r.k0w), &r.w0w))) return rc;
             if ((rc = up.upload16(pack_h2_wx(w2, &r.k2w), &r.w2w))) return rc;
         }
+#endif
     }
     return PMP_OK;
 }

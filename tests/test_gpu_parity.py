@@ -366,46 +366,17 @@ def test_device_calls_do_not_stall_the_host_and_the_guard_still_repairs(g1, orac
         e2.close()
 
 
-def test_winograd_form_of_the_trunk_convolutions(g1, oracle_lib):
-    """conv_f16x3_wx.hip (opt-in, pmp_debug_set_winograd): the 3x3 64->64 convolutions with a Winograd F(2,3) transform along x - 1.5x fewer
-    MFMAs, not bit-identical to the direct form but inside the same tolerance: logits within 1e-3 of the oracle for both components, split
-    flags bit-exact on the device logits, and the range guard still repairs a saturating net (a V beyond the fp16 range turns into NaN
-    outputs, which the NaN-aware flag catches)."""
-    from oracle import nets_torch as O
-    from pmp_vvc_tip2023_amd import engine, synth, weights as W
-    y, u, v = synth.recipe_r_blocks(40, 321)
+def test_product_library_ships_no_winograd_form():
+    """The Winograd-x form of the 3x3 64->64 convolutions (conv_f16x3_wx.hip) did not beat the direct kernels, so - like every other form
+    that lost its A/B - it is built into the measurement library only: the product library accepts "off" and refuses "on".  Its parity
+    checks (logits vs the oracle, flags bit-exact, range guard through it) run in tools/wx_probe.py against libpmp_hip_abl.so."""
+    from pmp_vvc_tip2023_amd import _lib, engine
     e2 = engine.Engine(0, allow_synthetic_mtt=True)
     try:
-        e2.set_precision("f16x3")
-        for comp in ("Luma", "Chroma"):
-            luma = comp == "Luma"
-            wq, _ = W.load_net_weights(comp + "_Q", 27)
-            wb, _ = W.load_net_weights(comp + "_MSBD", 27, allow_synthetic=True)
-            x = O.luma_input(y) if luma else O.chroma_input(y, u, v)
-            oq, obt, od = O.infer_qbd(wq, wb, x, luma)
-            e2._ck(e2.lib.pmp_debug_set_winograd(e2.h, 0))
-            direct = e2.infer_postprocess(comp, 27, y, u, v, want_logits=True)
-            e2._ck(e2.lib.pmp_debug_set_winograd(e2.h, 1))
-            hor, ver, q8, d8, qt, bt, dire = e2.infer_postprocess(comp, 27, y, u, v, want_logits=True)
-            err = max(np.abs(qt - oq).max(), np.abs(bt - obt).max(), np.abs(dire - od).max())
-            assert err < TOL, "%s logits off by %g in the Winograd form" % (comp, err)
-            assert not np.array_equal(bt, direct[5])              # it really is another kernel ...
-            assert np.abs(bt - direct[5]).max() < 2e-4            # ... with the same answer
-            oh, ov, oq8, od8 = oracle_lib.seq_post_process(qt, bt, dire, comp, 1, 64 * 40, 64, None)
-            assert np.array_equal(hor, oh) and np.array_equal(ver, ov) and np.array_equal(q8, oq8.astype(np.uint8)) and np.array_equal(d8, od8)
-            assert not e2.saturated()
-        # range guard through the Winograd kernels
-        yb = np.ascontiguousarray(g1["block_y"][:6])
-        w = _range_stress_weights()
-        wq, _ = W.load_net_weights("Luma_Q", 22)
-        oq, obt, od = O.infer_qbd(wq, w, O.luma_input(yb), True)
-        e2.load("Luma", 22)
-        e2.load_pretrain_model("Luma_MSBD", 22, w)
-        qt, bt, dire = e2.inference_pre_QBD("Luma", 22, yb)
-        assert e2.saturated() and e2.saturation_reruns() == 1
-        assert max(np.abs(qt - oq).max(), np.abs(bt - obt).max(), np.abs(dire - od).max()) < TOL
+        assert e2.lib.pmp_debug_set_winograd(e2.h, 0) == 0
+        assert e2.lib.pmp_debug_set_winograd(e2.h, 1) == -1           # PMP_E_INVALID
+        assert b"libpmp_hip_abl.so" in e2.lib.pmp_last_error(e2.h)
     finally:
-        e2._ck(e2.lib.pmp_debug_set_winograd(e2.h, 0))
         e2.close()
 
 
