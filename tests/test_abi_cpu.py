@@ -168,17 +168,17 @@ def test_product_library_has_no_ablation_knobs(lib):
     """The product library ships ONE form of every kernel: the A/B forms that lost their measurement (conv variants 1, 3-9), the
     timing-only builds (wrong results) and the PMP_CONV_VARIANT environment knob exist only in the measurement library
     libpmp_hip_abl.so (make abl; tools/variants_agree.py, tools/conv_ab.py).  Here the selector accepts the default and nothing else,
-    there is no process-wide variant state, and the 32x16-tile kernel is not in the code object."""
+    there is no process-wide variant state, and neither the 32x16-tile kernel nor the Winograd-x kernel is in the code object."""
     assert lib.pmp_debug_set_conv_variant(2) == 0
     for bad in (0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11, 18, 138, 1162, -1, 4096):
         assert lib.pmp_debug_set_conv_variant(bad) == -1, bad
     assert b"libpmp_hip_abl.so" in lib.pmp_last_error(None)
     blob = open(_lib.LIB_PATH, "rb").read()
     assert b"PMP_CONV_VARIANT" not in blob and b"g_conv_variant" not in blob
-    for sym in (b"conv_h2_t32", b"conv_h2_persist_kernel", b"conv_h2_ld_kernel"):
-        assert sym not in blob, sym
+    for sym in (b"conv_h2_t32", b"conv_h2_persist_kernel", b"conv_h2_ld_kernel", b"conv_h2_wx_kernel", b"pack_h2_wx"):
+        assert sym not in blob, sym                        # ... nor the Winograd-x experiment of round 3, nor its weight packer
     assert b"abl" not in lib.pmp_version()
-    assert os.path.getsize(_lib.LIB_PATH) < 2.4e6          # 2.78 MB with the notebook inside (round 2)
+    assert os.path.getsize(_lib.LIB_PATH) < 2.1e6          # 2.78 MB with the notebook inside (round 2)
 
 
 def test_pmpw_container_reader_matches_python(lib, tmp_path):
