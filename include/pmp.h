@@ -69,7 +69,9 @@ int pmp_destroy(pmp_ctx *ctx);
 
 /* pmp_destroy parks the context's activation workspace (up to 10 GB) for the next context created on the same device instead of
  * freeing it: a large hipMalloc right after a hipFree of that size stalls for 0.5-1.4 s now and then on MI355X (the freed memory is
- * still being cleared).  One parked buffer per device; pmp_trim() returns parked memory to the driver. */
+ * still being cleared).  One parked buffer per device; pmp_trim() returns parked memory to the driver - a host that destroys its
+ * context to hand the VRAM to another library calls it right after pmp_destroy.  pmp_trim leaves the calling thread's current
+ * device as it is. */
 int pmp_trim(void);
 
 /* Use the caller's hipStream_t (e.g. torch's current stream); NULL restores the context's own stream. */
@@ -101,9 +103,10 @@ int pmp_get_precision(const pmp_ctx *ctx);
  * (a NaN raises it too).  Every pmp_infer* call snapshots the flag behind its passes - stream-ordered, into pinned host memory -
  * and the snapshot is LOOKED AT LATER, so that the *_device entry points never stall the host: by the next call of the context
  * (polled: only snapshots that have landed), and by pmp_synchronize / pmp_get_saturation / any host-pointer call (waited for).
- *   PMP_SAT_RERUN (default)  a call whose flag fired is run AGAIN on the bf16x6 datapath (no range limit, fp32-equivalent) into
+ *   PMP_SAT_RERUN (default)  a call whose flag fired is run AGAIN on the exact fp32 MFMA datapath (fp32 range and arithmetic) into
  *                            the same output buffers, and every post-processing call that was enqueued after it is replayed in
- *                            order.  Consequence for *_device callers: outputs are FINAL once pmp_synchronize (or
+ *                            order (a later call whose logits are in the context's own buffers - no logit pointers passed - runs again too).
+ *                            Consequence for *_device callers: outputs are FINAL once pmp_synchronize (or
  *                            pmp_get_saturation) has returned - synchronising the stream yourself is enough only if you also
  *                            know the flag stayed down; inputs and outputs must stay untouched until then.  Host-pointer entry
  *                            points return final results, as before.

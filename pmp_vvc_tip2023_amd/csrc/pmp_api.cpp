@@ -185,8 +185,9 @@ static int count_pending_infer(const pmp_ctx *c)
 // Looks at the flag snapshots of the calls in flight, oldest first.  wait = false: only those whose event has completed (a later
 // call polling, no host stall); wait = true: all of them (pmp_synchronize, pmp_get_saturation, host-pointer calls).  The first
 // fired flag drains the stream once - from then on every later snapshot is final - and from there on, in order: a fired inference
-// call runs again on bf16x6, a post-processing call behind a re-run inference call is replayed.  Everything re-enqueued is ordered
-// on the stream; the caller synchronises if it needs the results on the host.
+// call runs again on the exact fp32 MFMA datapath, a later inference call that keeps its logits in the context's own buffers runs
+// again as it was (the re-run before it has overwritten them), a post-processing call behind a re-run is replayed.  Everything
+// re-enqueued is ordered on the stream; the caller synchronises if it needs the results on the host.
 static int resolve_pending(pmp_ctx *c, bool wait)
 {
     bool dirty = false;
@@ -211,10 +212,12 @@ static int resolve_pending(pmp_ctx *c, bool wait)
                     dirty = true;
                 }
                 c->sat_reruns += 1;
-                rc = p.rerun();
+                rc = p.rerun(true);
+            } else if (dirty && p.ctx_logits) {
+                rc = p.rerun(false);
             }
         } else if (dirty) {
-            rc = p.rerun();
+            rc = p.rerun(false);
         }
         if (p.ev) c->event_pool.push_back(p.ev);
         c->pending.pop_front();
@@ -224,7 +227,7 @@ static int resolve_pending(pmp_ctx *c, bool wait)
 }
 
 static int infer_device_impl(pmp_ctx *c, int comp, int qp, const uint8_t *by, const uint8_t *bu, const uint8_t *bv,
-                             int64_t n, float *qt, float *bt, float *dire)
+                             int64_t n, float *qt, float *bt, float *dire, bool ctx_logits = false)
 {
     if (comp != PMP_LUMA && comp != PMP_CHROMA) return set_err(c, PMP_E_INVALID, "pmp_infer: comp must be PMP_LUMA or PMP_CHROMA");
     if (n < 0 || !by || !qt || !bt || !dire || (comp == PMP_CHROMA && (!bu || !bv)))
@@ -239,7 +242,7 @@ static int infer_device_impl(pmp_ctx *c, int comp, int qp, const uint8_t *by, co
     rc = infer_passes(c, luma, *wq, *wb, by, bu, bv, n, qt, bt, dire);
     if (rc != PMP_OK || c->precision != PMP_PRECISION_F16X3 || c->sat_policy == PMP_SAT_IGNORE || n == 0) return rc;
     // f16x3 range guard: snapshot the flag behind this call's passes and reset it for the next call - all stream-ordered, the host
-    // does not wait.  Whoever looks at the snapshot later (resolve_pending) re-runs the call on bf16x6 if it fired.
+    // does not wait.  Whoever looks at the snapshot later (resolve_pending) re-runs the call on the fp32 MFMA datapath if it fired.
     if (count_pending_infer(c) >= PMP_SAT_SLOTS && (rc = resolve_pending(c, true)) != PMP_OK) return rc;
     unsigned *slot = c->h_sat + (c->sat_seq++ % PMP_SAT_SLOTS);
     *slot = 0;
@@ -248,10 +251,14 @@ static int infer_device_impl(pmp_ctx *c, int comp, int qp, const uint8_t *by, co
     hipEvent_t ev = get_event(c);
     if (e == hipSuccess) e = hipEventRecord(ev, c->stream);
     if (e != hipSuccess) { c->event_pool.push_back(ev); return hip_fail(c, e, "saturation flag snapshot"); }
-    c->pending.push_back(PendingCall{true, ev, slot, [=]() {
+    c->pending.push_back(PendingCall{true, ctx_logits, ev, slot, [=](bool fired) {
         NetWeights *rq = find_net(c, id_q, qp), *rb = find_net(c, id_b, qp);   // replacing a net settles first: still the same nets
         if (!rq || !rb) return set_err(c, PMP_E_NOWEIGHTS, "pmp_infer: weights vanished before the range-guard re-run");
-        c->precision = PMP_PRECISION_BF16X6;        // three bf16 terms: fp32's exponent range, fp32-equivalent products
+        // fired: the exact fp32 MFMA datapath - fp32's range, a bit-exact fmaf chain, and on the full-size campaign the closest of the
+        // three to the oracle (profiles/r03_parity_campaign.txt: 5.5e-4 against bf16x6's 8.9e-4 on the worst block); its speed does not
+        // matter for a call that is this rare.  Not fired: the call's logits were in the context's buffers, which an earlier re-run has
+        // overwritten - the same call again, on the datapath it ran on.
+        if (fired) c->precision = PMP_PRECISION_F32;
         const int r2 = infer_passes(c, luma, *rq, *rb, by, bu, bv, n, qt, bt, dire);
         c->precision = PMP_PRECISION_F16X3;
         return r2;
@@ -276,8 +283,24 @@ static int post_device_impl(pmp_ctx *c, int comp, const float *qt, const float *
     const int rc = post_launch(c, comp, qt, bt, dire, n, hor, ver, qt_u8, dire_i8, record_stride);
     // its logits may come from an inference call whose range flag has not been looked at yet: remember the call for the replay
     if (rc == PMP_OK && !c->pending.empty())
-        c->pending.push_back(PendingCall{false, nullptr, nullptr, [=]() { return post_launch(c, comp, qt, bt, dire, n, hor, ver, qt_u8, dire_i8, record_stride); }});
+        c->pending.push_back(PendingCall{false, false, nullptr, nullptr, [=](bool) { return post_launch(c, comp, qt, bt, dire, n, hor, ver, qt_u8, dire_i8, record_stride); }});
     return rc;
+}
+
+static int settle(pmp_ctx *c);
+
+// The context's own logit buffers (fused entry points called without logit pointers, host-pointer entry points).  Calls still in
+// flight may hold pointers into them for a range-guard re-run: they are settled BEFORE a buffer is regrown (and thereby freed).
+static int ensure_logits(pmp_ctx *c, int64_t n)
+{
+    const size_t need[3] = {(size_t)(n ? n : 1) * 64 * 4, (size_t)(n ? n : 1) * 768 * 4, (size_t)(n ? n : 1) * 768 * 4};
+    int rc;
+    if ((need[0] > c->d_logit[0].cap || need[1] > c->d_logit[1].cap || need[2] > c->d_logit[2].cap) && !c->pending.empty() &&
+        (rc = settle(c)) != PMP_OK)
+        return rc;
+    for (int i = 0; i < 3; ++i)
+        if ((rc = ensure(c, c->d_logit[i], need[i])) != PMP_OK) return rc;
+    return PMP_OK;
 }
 
 static int sync(pmp_ctx *c)
@@ -389,7 +412,7 @@ int pmp_destroy(pmp_ctx *c)
 int pmp_trim(void)
 {
     std::lock_guard<std::mutex> lk(g_park_mutex);
-    for (auto &kv : g_parked) { hipSetDevice(kv.first); if (kv.second.p) hipFree(kv.second.p); }
+    for (auto &kv : g_parked) if (kv.second.p) hipFree(kv.second.p);   // hipFree needs no current device: the caller's stays as it is
     g_parked.clear();
     return PMP_OK;
 }
@@ -519,10 +542,12 @@ int pmp_infer_postprocess_device(pmp_ctx *c, int comp, int qp, const uint8_t *by
 {
     CHECK_CTX(c);
     int rc;
-    if (!qt) { if ((rc = ensure(c, c->d_logit[0], (size_t)(n ? n : 1) * 64 * 4))) return rc; qt = (float *)c->d_logit[0].p; }
-    if (!bt) { if ((rc = ensure(c, c->d_logit[1], (size_t)(n ? n : 1) * 768 * 4))) return rc; bt = (float *)c->d_logit[1].p; }
-    if (!dire) { if ((rc = ensure(c, c->d_logit[2], (size_t)(n ? n : 1) * 768 * 4))) return rc; dire = (float *)c->d_logit[2].p; }
-    if ((rc = infer_device_impl(c, comp, qp, by, bu, bv, n, qt, bt, dire))) return rc;
+    const bool own = !qt || !bt || !dire;
+    if (own && (rc = ensure_logits(c, n))) return rc;
+    if (!qt) qt = (float *)c->d_logit[0].p;
+    if (!bt) bt = (float *)c->d_logit[1].p;
+    if (!dire) dire = (float *)c->d_logit[2].p;
+    if ((rc = infer_device_impl(c, comp, qp, by, bu, bv, n, qt, bt, dire, own))) return rc;
     return post_device_impl(c, comp, qt, bt, dire, n, hor, ver, qt_u8, dire_i8);
 }
 
@@ -546,11 +571,9 @@ int pmp_infer_postprocess_records_device(pmp_ctx *c, int comp, int qp, const uin
     CHECK_CTX(c);
     if (n == 0) return PMP_OK;   // an empty shard has no buffers at all
     int rc;
-    if ((rc = ensure(c, c->d_logit[0], (size_t)(n ? n : 1) * 64 * 4)) || (rc = ensure(c, c->d_logit[1], (size_t)(n ? n : 1) * 768 * 4)) ||
-        (rc = ensure(c, c->d_logit[2], (size_t)(n ? n : 1) * 768 * 4)))
-        return rc;
+    if ((rc = ensure_logits(c, n))) return rc;
     float *qt = (float *)c->d_logit[0].p, *bt = (float *)c->d_logit[1].p, *dire = (float *)c->d_logit[2].p;
-    if ((rc = infer_device_impl(c, comp, qp, by, bu, bv, n, qt, bt, dire))) return rc;
+    if ((rc = infer_device_impl(c, comp, qp, by, bu, bv, n, qt, bt, dire, true))) return rc;
     return post_records(c, comp, qt, bt, dire, n, rec);
 }
 
@@ -575,9 +598,7 @@ int pmp_infer(pmp_ctx *c, int comp, int qp, const uint8_t *by, const uint8_t *bu
     if (n == 0) return PMP_OK;
     int rc;
     if ((rc = stage_blocks(c, comp, by, bu, bv, n))) return rc;
-    if ((rc = ensure(c, c->d_logit[0], (size_t)n * 64 * 4)) || (rc = ensure(c, c->d_logit[1], (size_t)n * 768 * 4)) ||
-        (rc = ensure(c, c->d_logit[2], (size_t)n * 768 * 4)))
-        return rc;
+    if ((rc = ensure_logits(c, n))) return rc;
     float *dq = (float *)c->d_logit[0].p, *db = (float *)c->d_logit[1].p, *dd = (float *)c->d_logit[2].p;
     if ((rc = infer_device_impl(c, comp, qp, (const uint8_t *)c->d_in[0].p, (const uint8_t *)c->d_in[1].p,
                                 (const uint8_t *)c->d_in[2].p, n, dq, db, dd)))
@@ -616,6 +637,7 @@ int pmp_postprocess(pmp_ctx *c, int comp, const float *qt, const float *bt, cons
         return set_err(c, PMP_E_INVALID, "pmp_postprocess: null buffer or negative count");
     if (n == 0) return PMP_OK;
     int rc;
+    if ((rc = ensure_logits(c, n))) return rc;
     if ((rc = h2d(c, c->d_logit[0], qt, (size_t)n * 64 * 4)) || (rc = h2d(c, c->d_logit[1], bt, (size_t)n * 768 * 4)) ||
         (rc = h2d(c, c->d_logit[2], dire, (size_t)n * 768 * 4)) || (rc = alloc_out(c, n)))
         return rc;
@@ -635,9 +657,7 @@ int pmp_infer_postprocess(pmp_ctx *c, int comp, int qp, const uint8_t *by, const
     if (n == 0) return PMP_OK;
     int rc;
     if ((rc = stage_blocks(c, comp, by, bu, bv, n)) || (rc = alloc_out(c, n))) return rc;
-    if ((rc = ensure(c, c->d_logit[0], (size_t)n * 64 * 4)) || (rc = ensure(c, c->d_logit[1], (size_t)n * 768 * 4)) ||
-        (rc = ensure(c, c->d_logit[2], (size_t)n * 768 * 4)))
-        return rc;
+    if ((rc = ensure_logits(c, n))) return rc;
     float *dq = (float *)c->d_logit[0].p, *db = (float *)c->d_logit[1].p, *dd = (float *)c->d_logit[2].p;
     if ((rc = infer_device_impl(c, comp, qp, (const uint8_t *)c->d_in[0].p, (const uint8_t *)c->d_in[1].p,
                                 (const uint8_t *)c->d_in[2].p, n, dq, db, dd)))

@@ -96,13 +96,15 @@ struct KTimeRec { hipEvent_t a, b; double flops; };
 
 // f16x3 range guard, deferred (include/pmp.h): every inference call snapshots the device flag into a pinned host word behind its
 // passes and records an event; the word is read when the event has completed - at a later call (polled), at pmp_synchronize /
-// pmp_get_saturation or at the end of a host-pointer call (waited for).  A call whose flag fired is run again on bf16x6 and every
-// post-processing call enqueued after it is replayed, in order, on the same buffers.
+// pmp_get_saturation or at the end of a host-pointer call (waited for).  A call whose flag fired is run again on the fp32 MFMA
+// datapath and every post-processing call enqueued after it is replayed, in order, on the same buffers; later inference calls whose
+// logits live in the context's own buffers (which the re-run has overwritten) run again too.
 struct PendingCall {
     bool infer;                       // inference (has a flag snapshot) or a post-processing call recorded for replay
+    bool ctx_logits;                  // infer: its logits are in c->d_logit, shared by every call that passes no logit pointers
     hipEvent_t ev;                    // infer: completes when the snapshot has landed
     unsigned *slot;                   // infer: pinned host word
-    std::function<int()> rerun;       // infer: the same call on bf16x6;  post: the same call again
+    std::function<int(bool)> rerun;   // infer: the same call, on fp32 MFMA if its flag fired;  post: the same call again
 };
 
 }  // namespace pmp

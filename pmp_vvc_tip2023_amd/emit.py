@@ -6,6 +6,9 @@ six sections (hor, ver, qt, dire 0..2) is row-major, so a run of whole BLOCK ROW
 Line lengths vary ("-1\\n" vs "0\\n"), so the ranks exchange the exact byte count of every (block row, section) pair - one
 all-reduce of an int64[frames * H/64, 6] table per file, a few KB - derive every range's offset with an exclusive scan in file
 order, and write concurrently with pwrite.  The bytes are identical to the single-writer file (a19): tests/test_emit_cpu.py.
+Every rank writes into `<name>.part`; rank 0 renames it to the final name in drain(), after a barrier behind every rank's writes: a
+job that dies half-way (the launcher kills the peers of a failed rank) leaves a `.part` file, never a full-size PartitionMat.txt with
+holes that VTM's parser would read as data.
 
 The unit of sharding is the block row (H/64 per frame), not the frame: real jobs have fewer sub-sampled frames than GPUs
 (ssRatio 30), and 9 frames on 8 ranks would otherwise leave one rank with twice the work.
@@ -71,6 +74,7 @@ class ShardEmitter:
         self.threads = threads
         self.pool = ThreadPoolExecutor(max_workers=threads)
         self.writes = []
+        self.renames = []            # rank 0: (part, final) of the files whose writes are queued
         self.bytes_written = 0
 
     # ---------------------------------------------------------------------------------------------------------------- phases
@@ -100,23 +104,32 @@ class ShardEmitter:
             done.append((f, a, b, buf, sizes))
         sizes_all = parallel.all_reduce_sum(local, self.device) if self.world > 1 else local
         offs, total = section_offsets(sizes_all, p.frames, p.bh)
+        part = p.path + ".part"
         if self.rank == 0:      # creates the file / cuts a longer stale one; concurrent pwrites of other ranks all lie below `total`
-            fd = os.open(p.path, os.O_WRONLY | os.O_CREAT, 0o644)
+            fd = os.open(part, os.O_WRONLY | os.O_CREAT, 0o644)
             try:
                 os.ftruncate(fd, total)
             finally:
                 os.close(fd)
+            self.renames.append((part, p.path))
         for item in done:
-            self.writes.append(self.pool.submit(self._write_piece, p.path, offs, item))
+            self.writes.append(self.pool.submit(self._write_piece, part, offs, item))
         if p.binary:
             self._binary(p)
         p.rec = None
         return total
 
     def drain(self):
+        """Called at the same points on every rank (end of a sequence, close): waits for this rank's writes, then - behind a barrier
+        that puts EVERY rank's writes before it - rank 0 gives the finished files their final names."""
         for w in self.writes:
             self.bytes_written += w.result()
         self.writes = []
+        if self.world > 1:
+            parallel.all_reduce_sum(np.zeros(1, np.int64), self.device)      # barrier on the backend the job runs on
+        for part, final in self.renames:
+            os.replace(part, final)
+        self.renames = []
 
     def close(self):
         self.drain()
@@ -146,7 +159,8 @@ class ShardEmitter:
 
     def _binary(self, p):
         """Binary side channel (include/pmp.h, PMPB1): fixed-size matrices, so the offsets need no exchange."""
-        path = p.path[:-4] + ".pmpb"
+        final = p.path[:-4] + ".pmpb"
+        path = final + ".part"
         R, Cc = 16 * p.bh, 16 * p.bw
         per = 5 * R * Cc + R * Cc // 4
         if self.rank == 0:
@@ -157,6 +171,7 @@ class ShardEmitter:
                 _pwrite_all(fd, memoryview(hdr), 0)
             finally:
                 os.close(fd)
+            self.renames.append((path, final))
         rec, g_lo, bw = np.array(p.rec), p.g_lo, p.bw     # own copy: these jobs outlive finish(), the caller's buffer does not
 
         def job(f, a, b):

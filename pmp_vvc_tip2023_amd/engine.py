@@ -78,7 +78,7 @@ class Engine:
 
     def set_saturation_policy(self, policy):
         """f16x3 range guard (include/pmp.h): 'rerun' (default: a call whose activations left the fp16 range is run again on
-        bf16x6), 'error' (PMP_E_RANGE instead) or 'ignore' (no check, fully asynchronous device calls)."""
+        the exact fp32 MFMA datapath), 'error' (PMP_E_RANGE instead) or 'ignore' (no check, fully asynchronous device calls)."""
         self._ck(self.lib.pmp_set_saturation_policy(self.h, {"rerun": 0, "error": 1, "ignore": 2}[policy]))
 
     def saturated(self):

@@ -304,6 +304,7 @@ def inference_VVC_seqs(args):
     parallel.init_process_group(device)
     if world > 1:
         info = parallel.preflight(device)            # a broken RCCL / IPC setup fails HERE, with a message, not in the first real pass
+        parallel.relax_timeout()                     # PMP_DIST_TIMEOUT_S bounded the rendezvous; the passes' collectives get PMP_DIST_COLLECTIVE_TIMEOUT_S
         if rank == 0:
             print("ranks: %d (%s), first collective %.1f ms" % (info["ranks"], info["backend"], info["ms"]), flush=True)
 
@@ -459,7 +460,7 @@ def inference_VVC_seqs(args):
             seqs_net_time[si, qi, comp_id] = time.perf_counter() - t0
             if eng.saturation_reruns() != reruns:   # f16x3 range guard (include/pmp.h): results are right, the pass cost 3x
                 print("WARNING: rank %d: %s %s QP%d drove an activation beyond the fp16 range of the f16x3 datapath; the pass was "
-                      "re-run on bf16x6 (consider --precision bf16x6 for this model)" % (rank, sq["name"], comp, qp), file=sys.stderr, flush=True)
+                      "re-run on the fp32 datapath (consider --precision bf16x6 for this model)" % (rank, sq["name"], comp, qp), file=sys.stderr, flush=True)
             t0 = tw = time.perf_counter()
             if rank == 0:
                 print("Save:", save_path, flush=True)

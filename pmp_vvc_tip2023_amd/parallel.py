@@ -50,24 +50,44 @@ def unpack_records(rec):
             rec[:, 512:576].reshape(n, 8, 8).copy(), rec[:, 576:].copy().view(np.int8).reshape(n, 3, 16, 16))
 
 
-INIT_TIMEOUT_S = 180      # rendezvous + first collective: a rank that never arrives becomes an error, not a hang
+INIT_TIMEOUT_S = 180           # rendezvous + preflight: a rank that never arrives becomes an error, not a hang
+COLLECTIVE_TIMEOUT_S = 1800    # steady state: a rank slowed by disk, a long first touch or a range-guard re-run is late, not missing
 
 
-def init_process_group(device=None, timeout_s=None):
-    """Join the torchrun rendezvous (no-op for world 1).  Returns (rank, world, local_rank).  The timeout bounds the rendezvous
-    and every later collective (PMP_DIST_TIMEOUT_S overrides): a missing rank ends the job with an error instead of hanging it."""
+def init_process_group(device=None, timeout_s=None, force=False):
+    """Join the torchrun rendezvous (no-op for world 1 unless `force` or PMP_DIST_FORCE=1: a one-rank group, which is how the
+    single-GPU test box executes the RCCL code path).  Returns (rank, world, local_rank).  The short timeout (PMP_DIST_TIMEOUT_S)
+    bounds the rendezvous and the preflight only: relax_timeout() raises it for the job's own collectives."""
     rank, world, local = env_world()
-    if world > 1:
+    force = force or os.environ.get("PMP_DIST_FORCE") == "1"
+    if world > 1 or force:
         import datetime
         import torch
         import torch.distributed as dist
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
             backend = os.environ.get("PMP_DIST_BACKEND") or ("nccl" if (device is not None and torch.cuda.is_available()) else "gloo")
             kw = {"device_id": device} if backend == "nccl" else {}
             t = float(os.environ.get("PMP_DIST_TIMEOUT_S", timeout_s or INIT_TIMEOUT_S))
             dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=t), **kw)
     return rank, world, local
+
+
+def relax_timeout():
+    """After the preflight: the job's own collectives (size all-reduces, the gather, closing barriers) get the steady-state timeout
+    (PMP_DIST_COLLECTIVE_TIMEOUT_S, default 1800 s).  A rank that DIES is noticed by the launcher at once (spawn_ranks polls every
+    rank), so the long bound only ever covers ranks that are slow.  Returns the seconds in force (None without a process group)."""
+    import datetime
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return None
+    t = float(os.environ.get("PMP_DIST_COLLECTIVE_TIMEOUT_S", COLLECTIVE_TIMEOUT_S))
+    try:
+        dist.distributed_c10d._set_pg_timeout(datetime.timedelta(seconds=t), None)     # RCCL and gloo process groups both honour it
+    except Exception:                                          # noqa: BLE001 - a torch without it: the init timeout stays in force
+        return float(os.environ.get("PMP_DIST_TIMEOUT_S", INIT_TIMEOUT_S))
+    return t
 
 
 def preflight(device=None):
@@ -77,7 +97,7 @@ def preflight(device=None):
     import time
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return {"ranks": 1, "backend": None, "ms": 0.0}
     rank, world, backend = dist.get_rank(), dist.get_world_size(), dist.get_backend()
     dev = device if backend == "nccl" else torch.device("cpu")
@@ -107,7 +127,8 @@ def spawn_ranks(cmd, n, env_extra=None, capture_rank0=False, poll_s=0.05):
     """Start n fresh rank processes of `cmd` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; the caller has made no GPU call -
     a process that has initialised HIP must never be forked or re-executed) and watch ALL of them: the first rank that exits
     non-zero ends the job - the others, which would sit in a collective until its timeout, are killed by PID - and its code is
-    returned.  capture_rank0: rank 0's stdout is collected (on a thread, so a full pipe never blocks it) and returned.
+    returned.  Rank 0 inherits this process's stdout (the reference driver prints its progress there), the other ranks' stdout goes
+    to stderr; capture_rank0: rank 0's stdout is collected instead (on a thread, so a full pipe never blocks it) and returned.
     Returns (exit code, rank-0 stdout bytes or None)."""
     import socket
     import subprocess
@@ -123,7 +144,7 @@ def spawn_ranks(cmd, n, env_extra=None, capture_rank0=False, poll_s=0.05):
     procs = []
     for r in range(n):
         procs.append(subprocess.Popen(list(cmd), env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
-                                      stdout=subprocess.PIPE if (capture_rank0 and r == 0) else sys.stderr, stderr=sys.stderr))
+                                      stdout=(subprocess.PIPE if capture_rank0 else sys.stdout) if r == 0 else sys.stderr, stderr=sys.stderr))
     chunks = []
     reader = None
     if capture_rank0:
@@ -167,7 +188,7 @@ def all_reduce_sum(arr, device=None):
     import torch
     import torch.distributed as dist
     a = np.ascontiguousarray(arr, np.int64)
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():                              # (a forced one-rank group does run the collective)
         return a
     t = torch.from_numpy(a.copy())
     if dist.get_backend() == "nccl":
@@ -187,7 +208,7 @@ def gather_records(local_rec, n_total, device=None):
     import torch
     import torch.distributed as dist
     is_tensor = isinstance(local_rec, torch.Tensor)
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():                              # (a forced one-rank group does run the collective)
         return local_rec.cpu().numpy() if is_tensor else np.ascontiguousarray(local_rec)
     rank, world = dist.get_rank(), dist.get_world_size()
     counts = shard_counts(n_total, world)

@@ -133,3 +133,26 @@ def test_four_ranks_gloo_ragged_frames_equal_one_writer(tmp_path):
     for tag in cases:
         assert (tmp_path / (tag + "_PartitionMat.txt")).read_bytes() == (tmp_path / (tag + "_ref.txt")).read_bytes(), tag
         assert (tmp_path / (tag + "_PartitionMat.pmpb")).read_bytes() == (tmp_path / (tag + "_ref.pmpb")).read_bytes(), tag
+
+
+def test_unfinished_job_leaves_a_part_file_not_a_holey_final_file(tmp_path):
+    """a rank that dies between finish() and drain() must not leave a full-size PartitionMat.txt with NUL holes under the final
+    name.  Writes go to <name>.part; the final name appears in drain(), behind every rank's writes - and an older complete file stays
+    intact until then."""
+    F, H, W = 2, 128, 128
+    bh, bw = H // 64, W // 64
+    rec, (hor, ver, q8, d8) = _records(F * bh * bw, 31)
+    out = tmp_path / "seq_Luma_QP22_PartitionMat.txt"
+    out.write_bytes(b"an older, complete file\n")
+    em = emit.ShardEmitter(threads=1)
+    p = em.start(str(out), F, H, W, 0, F * bh, rec, binary=True)
+    em.finish(p)
+    for w in em.writes:                                      # the writes themselves are done - the job "dies" before drain()
+        w.result()
+    assert out.read_bytes() == b"an older, complete file\n"
+    assert os.path.exists(str(out) + ".part") and not os.path.exists(str(tmp_path / "seq_Luma_QP22_PartitionMat.pmpb"))
+    em.close()                                               # the surviving path: drain() renames
+    ref = tmp_path / "ref.txt"
+    E.write_partition_file(str(ref), F, H, W, hor, ver, q8, d8)
+    assert out.read_bytes() == ref.read_bytes() and not os.path.exists(str(out) + ".part")
+    assert os.path.exists(str(tmp_path / "seq_Luma_QP22_PartitionMat.pmpb")) and not os.path.exists(str(tmp_path / "seq_Luma_QP22_PartitionMat.pmpb.part"))

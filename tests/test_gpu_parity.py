@@ -238,7 +238,8 @@ def _range_stress_weights(K=2.0 ** 17):
 def test_f16x3_range_guard(g1):
     """f16x3 carries activations as two fp16 terms, so values beyond +-65504 would be clamped (include/pmp.h).  The guard must
     (i) notice it, (ii) under the default policy return logits that are RIGHT (within 1e-3 of the oracle, by re-running the call
-    on bf16x6), (iii) return PMP_E_RANGE under PMP_SAT_ERROR, and (iv) under PMP_SAT_IGNORE still never produce inf/NaN."""
+    on the exact fp32 MFMA datapath - which on the full-size campaign is the datapath closest to the oracle, 1.8x inside the tolerance
+    on its worst block where bf16x6 is 1.1x), (iii) return PMP_E_RANGE under PMP_SAT_ERROR, and (iv) under PMP_SAT_IGNORE still never produce inf/NaN."""
     from oracle import nets_torch as O
     from pmp_vvc_tip2023_amd import _lib, engine, weights as W
     y = np.ascontiguousarray(g1["block_y"][:6])
@@ -252,10 +253,14 @@ def test_f16x3_range_guard(g1):
         e2.load("Luma", 22)                                    # real QT net; MTT net replaced below
         assert not e2.saturated() and e2.saturation_reruns() == 0
         e2.load_pretrain_model("Luma_MSBD", 22, w)
-        qt, bt, dire = e2.inference_pre_QBD("Luma", 22, y)     # default policy: re-run on bf16x6
+        qt, bt, dire = e2.inference_pre_QBD("Luma", 22, y)     # default policy: re-run on fp32 MFMA
         assert e2.saturated() and e2.saturation_reruns() == 1
         err = max(np.abs(qt - oq).max(), np.abs(bt - obt).max(), np.abs(dire - odire).max())
         assert err < TOL, "range guard re-run is off by %g" % err
+        e2.set_precision("fp32")                               # the re-run IS the fp32 datapath: same bits
+        qf, bf, df = e2.inference_pre_QBD("Luma", 22, y)
+        assert np.array_equal(qf, qt) and np.array_equal(bf, bt) and np.array_equal(df, dire), "the guard's re-run is not the fp32 datapath"
+        e2.set_precision("f16x3")
         hor, ver, q8, d8, qt2, bt2, dire2 = e2.infer_postprocess("Luma", 22, y, want_logits=True)   # the fused entry point too
         assert e2.saturation_reruns() == 2 and np.array_equal(bt2, bt) and np.array_equal(dire2, dire)
         e2.set_saturation_policy("error")
@@ -283,7 +288,7 @@ def test_f16x3_range_guard(g1):
 def test_device_calls_do_not_stall_the_host_and_the_guard_still_repairs(g1, oracle_lib):
     """The *_device entry points stay asynchronous under the default range-guard policy (include/pmp.h): each call snapshots the
     flag behind its passes and returns; the snapshot is looked at by a later call / pmp_synchronize, which re-runs a saturated
-    call on bf16x6 and replays the post-processing enqueued behind it.
+    call on the fp32 MFMA datapath and replays the post-processing enqueued behind it.
       (i) two device calls back to back return to the host in a fraction of the time the GPU needs for them (event timestamps);
       (ii) call A on range-stress weights (saturates) followed at once by call B on ordinary weights: after ONE pmp_synchronize
            both have oracle-correct logits and flags, exactly one re-run was counted;
@@ -354,6 +359,33 @@ def test_device_calls_do_not_stall_the_host_and_the_guard_still_repairs(g1, orac
         assert e2.saturation_reruns() == 1
         for a, b in zip(A, Cc):
             assert torch.equal(a, b)
+        # ---- (iv) both calls keep their logits in the CONTEXT's buffers (the record entry point passes no logit pointers): the re-run of A
+        #      overwrites them, so B - ordinary weights, flag down - has to be run again before its post-processing is replayed; and a B
+        #      with more blocks than A regrows those buffers, which must not happen under A's pending re-run.
+        for nb in (6, 2100):                                      # 2100 > the 2048 blocks of (i): B regrows the context's logit buffers
+            yb2, _, _ = synth.recipe_r_blocks(nb, 501)
+            yb2[:6] = yb
+            d_yb2 = torch.from_numpy(yb2).to(dev)
+            e2.clear_saturation()
+            ra = torch.zeros((6, 1344), dtype=torch.uint8, device=dev)
+            rb = torch.zeros((nb, 1344), dtype=torch.uint8, device=dev)
+            e2.infer_postprocess_records_device("Luma", 22, d_yb.data_ptr(), None, None, 6, ra.data_ptr())
+            e2.infer_postprocess_records_device("Luma", 27, d_yb2.data_ptr(), None, None, nb, rb.data_ptr())
+            e2.synchronize()
+            assert e2.saturation_reruns() == 1
+            # each call on its own: the reference for the pair in flight
+            e2.clear_saturation()
+            want_a = torch.empty((6, 1344), dtype=torch.uint8, device=dev)
+            want_b = torch.empty((nb, 1344), dtype=torch.uint8, device=dev)
+            e2.infer_postprocess_records_device("Luma", 22, d_yb.data_ptr(), None, None, 6, want_a.data_ptr())
+            e2.synchronize()
+            e2.infer_postprocess_records_device("Luma", 27, d_yb2.data_ptr(), None, None, nb, want_b.data_ptr())
+            e2.synchronize()
+            assert e2.saturation_reruns() == 1
+            for a4, w4 in zip(A[:4], (want_a[:, :256], want_a[:, 256:512], want_a[:, 512:576], want_a[:, 576:].view(torch.int8))):
+                assert torch.equal(a4, w4)                         # the record fields are the four arrays of (ii)
+            assert torch.equal(ra, want_a), "records of the saturating call A differ after the deferred re-run (%d blocks in B)" % nb
+            assert torch.equal(rb, want_b), "records of the ordinary call B were overwritten by A's re-run (%d blocks in B)" % nb
         # ---- the error policy reports at the call that looks at the flag
         from pmp_vvc_tip2023_amd import _lib
         e2.set_saturation_policy("error")

@@ -1,0 +1,163 @@
+"""GPU tests at the sizes and world sizes the driver's round-end runs use:
+  * the logit TAIL at BASELINE.json configs[1]'s real size - 4096 fresh blocks, default datapath - against the torch oracle, for the two
+    worst-conditioned nets (Luma QP22, QP27), with the fp32 MFMA datapath (the range guard's re-run) on the same blocks;
+  * a dress rehearsal of world size 8 on the ONE GPU of the test box (gloo carries the collectives): bench.py --gpus 8 and the driver
+    --gpus 8 on a ragged geometry, files byte-identical to one rank;
+  * RCCL itself on the hardware that is there: a one-rank "nccl" process group (device_id=) through parallel.preflight,
+    parallel.gather_records on a CUDA tensor, parallel.all_reduce_sum, and bench.py's device-tensor gather on its side stream."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 1e-3
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "PMP_DIST_FORCE")}
+    env.update(PYTHONPATH=ROOT, **extra)
+    return env
+
+
+# ------------------------------------------------------------------------------------------------ the tail at full size
+@pytest.mark.parametrize("qp", [22, 27])
+def test_full_size_logit_tail_default_datapath_and_guard_fallback(qp):
+    """4096 fresh recipe-R luma blocks (the campaign's seeds, tests/campaign_gpu.py): max |logit - oracle| < 1e-3 on the default f16x3
+    datapath and on the exact fp32 MFMA datapath the range guard falls back to.  The 512-block tests sit at 1.9e-4; the tail at this
+    size is 6.2e-4 / 5.6e-4 (profiles/r03_parity_campaign.txt) - Luma_Q's conditioning at low QP, the torch oracle itself is 3.3e-4
+    from fp64-accumulated convolutions on those blocks - so this is the test that notices a kernel change eating the margin:
+    it fails above 7.5e-4 although the tolerance is 1e-3."""
+    from oracle import nets_torch as O
+    from pmp_vvc_tip2023_amd import engine, synth, weights as W
+    n = 4096
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    y, _, _ = synth.recipe_r_blocks(n, 5000 + qp)
+    wq, _ = W.load_net_weights("Luma_Q", qp)
+    wbd, _ = W.load_net_weights("Luma_MSBD", qp, allow_synthetic=True)
+    oq, obt, od = O.infer_qbd(wq, wbd, O.luma_input(y), True, batch=64)
+    e = engine.Engine(0, allow_synthetic_mtt=True)
+    try:
+        out = {}
+        for prec in ("f16x3", "fp32"):
+            e.set_precision(prec)
+            qt, bt, dire = e.inference_pre_QBD("Luma", qp, y)
+            assert not e.saturated()
+            per_block = np.maximum(np.abs(qt - oq).reshape(n, -1).max(1),
+                                   np.maximum(np.abs(bt - obt).reshape(n, -1).max(1), np.abs(dire - od).reshape(n, -1).max(1)))
+            out[prec] = per_block
+            print("\n  Luma QP%d %-5s 4096 blocks: max |logit - oracle| %.2e (margin %.2fx inside 1e-3), per block median %.1e p99 %.1e p99.9 %.1e"
+                  % (qp, prec, per_block.max(), TOL / per_block.max(), np.median(per_block), np.quantile(per_block, 0.99),
+                     np.quantile(per_block, 0.999)), flush=True)
+        for prec, pb in out.items():
+            assert pb.max() < TOL, "Luma QP%d on %s: logits off by %g" % (qp, prec, pb.max())
+        assert out["f16x3"].max() < 7.5e-4, "the default datapath's tail moved: %.2e (round 3: 6.2e-4 / 5.6e-4)" % out["f16x3"].max()
+        assert np.quantile(out["f16x3"], 0.99) < 3.5e-4
+        assert out["fp32"].max() < 6.5e-4, "the range guard's fallback datapath is %.2e from the oracle (round 3: 5.5e-4)" % out["fp32"].max()
+    finally:
+        e.close()
+
+
+# ------------------------------------------------------------------------------------------------ world size 8, rehearsed on one GPU
+def test_bench_world8_rehearsal():
+    """`python bench.py --gpus 8` as its own launcher: eight fresh rank processes share the box's GPU (gloo), one JSON line with
+    n_gpus = 8, eight times the blocks, and the multi_gpu diagnostics of all eight ranks."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "16",
+                        "--cpu-sample", "0", "--no-extras"], capture_output=True, text=True, timeout=1500, env=_clean_env(PMP_DIST_BACKEND="gloo"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["blocks_per_gpu"] == 16 and d["config"]["global_blocks"] == 128 and d["scaling"] == "weak"
+    m = d["multi_gpu"]
+    assert d["rccl_ranks"] == 8 and m["rccl_ranks"] == 8 and m["backend"] == "gloo" and m["gather_bytes_per_step"] == 8 * 16 * 1344
+    assert len(m["ms_per_step_by_rank"]) == 8 and all(t > 0 for t in m["ms_per_step_by_rank"]) and len(m["gather_ms_by_rank"]) == 8
+    assert "preflight ok: 8 ranks" in r.stderr
+    assert d["value"] > 0 and abs(d["value"] - 128 / 4.0 / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]
+
+
+def test_driver_world8_rehearsal_ragged(tmp_path):
+    """The driver with --gpus 8 on a geometry that does not divide: 9 sub-sampled frames of 5 x 3 blocks = 27 block rows over 8 ranks
+    (three ranks take 4 rows, five take 3; frames straddle ranks).  Sharded emission and --emit gather both write the bytes of one rank."""
+    from pmp_vvc_tip2023_amd import inference_qbd as D, synth
+    inp = tmp_path / "in"; cfg = tmp_path / "cfg"
+    inp.mkdir(); cfg.mkdir()
+    w, h, fr = 320, 192, 9
+    with open(inp / "table.txt", "w") as f:
+        f.write("SeqR,SeqR_320x192_30.yuv,%d,%d,%d,30\n#end!!!!\n" % (w, h, fr))
+    y, u, v = synth.recipe_r_frames(fr, h, w, 191)
+    with open(inp / "SeqR_320x192_30.yuv", "wb") as f:
+        for i in range(fr):
+            f.write(y[i].tobytes()); f.write(u[i].tobytes()); f.write(v[i].tobytes())
+    with open(cfg / "SeqR.cfg", "w") as f:
+        f.write("InputFile : SeqR_320x192_30.yuv\nInputBitDepth : 8\n")
+    common = ["--inputDir", str(inp), "--seqTable", "table.txt", "--cfgDir", str(cfg), "--ssRatio", "1", "--seqNum", "1", "--qps", "22", "--allowSyntheticMTT"]
+    D.main(["--jobID", "one", "--outDir", str(tmp_path / "o1")] + common)
+    d1 = tmp_path / "o1" / "one" / "PartitionMat"
+    names = sorted(os.listdir(d1))
+    assert len(names) == 2
+    for job, extra in (("w8", []), ("w8g", ["--emit", "gather"])):
+        r = subprocess.run([sys.executable, "-m", "pmp_vvc_tip2023_amd.inference_qbd", "--jobID", job, "--outDir", str(tmp_path / job), "--gpus", "8"]
+                           + extra + common, env=_clean_env(PMP_DIST_BACKEND="gloo"), cwd=ROOT, capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        assert "ranks: 8 (gloo)" in r.stdout                      # rank 0's progress lines arrive on the launcher's stdout
+        dn = tmp_path / job / job / "PartitionMat"
+        assert names == sorted(os.listdir(dn))
+        for nme in names:
+            assert open(d1 / nme, "rb").read() == open(dn / nme, "rb").read(), (job, nme)
+
+
+# ------------------------------------------------------------------------------------------------ RCCL on the box that is there
+_RCCL_ONE_RANK = r"""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+from pmp_vvc_tip2023_amd import parallel
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+rank, world, local = parallel.init_process_group(dev, force=True)
+assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == 1
+info = parallel.preflight(dev)                                   # gather + all_reduce of device tensors, contents verified
+assert info["ranks"] == 1 and info["backend"] == "nccl", info
+assert parallel.relax_timeout() == 1800.0
+rec = torch.randint(0, 255, (37, 1344), dtype=torch.uint8, device=dev)
+got = parallel.gather_records(rec, 37, dev)                      # the device-tensor branch: RCCL gather, one D2H on rank 0
+assert isinstance(got, np.ndarray) and np.array_equal(got, rec.cpu().numpy())
+got = parallel.gather_records(rec.cpu().numpy(), 37, dev)        # numpy in: staged to the device first
+assert np.array_equal(got, rec.cpu().numpy())
+tab = np.arange(24, dtype=np.int64).reshape(4, 6)
+assert np.array_equal(parallel.all_reduce_sum(tab, dev), tab)    # the sharded emission's size table
+dist.barrier()
+torch.cuda.synchronize(dev)
+dist.destroy_process_group()
+print("RCCL one-rank ok: preflight %.1f ms" % info["ms"])
+"""
+
+
+def test_rccl_one_rank_process_group():
+    """Nothing in the multi-GPU path had ever touched RCCL on hardware.  A one-rank "nccl" group on the test
+    box's GPU loads librccl, creates the communicator with device_id= as parallel.init_process_group does for N ranks, and runs the
+    device-tensor branches of preflight / gather_records / all_reduce_sum.  Fresh process: never a GPU-touched process re-executed."""
+    r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK], env=_clean_env(PMP_DIST_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "RCCL one-rank ok" in r.stdout
+
+
+def test_bench_rccl_branch_one_rank():
+    """bench.py with PMP_DIST_FORCE=1: the N > 1 step - records gathered as device tensors over RCCL on the bench's side stream,
+    events around the collective - on a one-rank group.  The line says backend nccl, rccl_ranks 1."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "64", "--cpu-sample", "0",
+                        "--no-extras"], capture_output=True, text=True, timeout=900,
+                       env=_clean_env(PMP_DIST_FORCE="1", PMP_DIST_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
+    m = d["multi_gpu"]
+    assert d["n_gpus"] == 1 and m["backend"] == "nccl" and m["rccl_ranks"] == 1 and m["gather_bytes_per_step"] == 64 * 1344
+    assert m["gather_ms"] > 0 and "preflight ok: 1 ranks over nccl" in r.stderr

@@ -188,3 +188,51 @@ def test_preflight_and_size_table_reduce_over_gloo(tmp_path):
     script.write_text(WORKER_P % {"root": ROOT})
     rc, _ = parallel.spawn_ranks([sys.executable, str(script)], 2, env_extra={"OMP_NUM_THREADS": "1"})
     assert rc == 0
+
+
+ONE_RANK = r"""
+import sys
+import numpy as np
+import torch
+import torch.distributed as dist
+from pmp_vvc_tip2023_amd import parallel
+rank, world, local = parallel.init_process_group(None, force=True)     # a one-rank group: the collectives below really run
+assert (rank, world) == (0, 1) and dist.is_initialized() and dist.get_backend() == "gloo"
+info = parallel.preflight(None)
+assert info["ranks"] == 1 and info["backend"] == "gloo"
+assert parallel.relax_timeout() == 1800.0
+rec = np.random.default_rng(0).integers(0, 255, (9, 1344)).astype(np.uint8)
+assert np.array_equal(parallel.gather_records(rec, 9), rec)
+assert np.array_equal(parallel.gather_records(torch.from_numpy(rec), 9), rec)
+t = np.arange(12, dtype=np.int64).reshape(2, 6)
+assert np.array_equal(parallel.all_reduce_sum(t), t)
+dist.destroy_process_group()
+assert parallel.preflight(None) == {"ranks": 1, "backend": None, "ms": 0.0} and parallel.relax_timeout() is None
+print("one-rank ok")
+"""
+
+
+def test_forced_one_rank_group_runs_the_collectives(tmp_path):
+    """PMP_DIST_FORCE / force=True: with a process group present the helpers take the collective path even at world size 1 - the same
+    switch the GPU box uses to run the RCCL branch on its single GPU (tests/test_gpu_scale.py)."""
+    import subprocess, sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        env["MASTER_PORT"] = str(s.getsockname()[1])
+    env.update(PYTHONPATH=ROOT, PMP_DIST_BACKEND="gloo", PMP_DIST_COLLECTIVE_TIMEOUT_S="1800")
+    r = subprocess.run([sys.executable, "-c", ONE_RANK], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "one-rank ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_spawn_ranks_rank0_prints_on_the_launchers_stdout(tmp_path):
+    """ADVICE r3: the self-launched driver's progress lines (rank 0's 'Save:', 'Sum time') belong on stdout, as the reference prints them;
+    the other ranks' stdout goes to stderr."""
+    import subprocess, sys
+    prog = ("import sys; sys.path.insert(0, %r)\n"
+            "from pmp_vvc_tip2023_amd import parallel\n"
+            "rc, out = parallel.spawn_ranks([sys.executable, '-c', 'import os; print(\"hello from rank\", os.environ[\"RANK\"])'], 2)\n"
+            "assert out is None\nsys.exit(rc)\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.strip() == "hello from rank 0" and "hello from rank 1" in r.stderr
