@@ -237,6 +237,13 @@ int pmp_debug_set_conv_variant(int variant);
  *      product library accepts on = 0 and answers PMP_E_INVALID to anything else. ---- */
 int pmp_debug_set_winograd(pmp_ctx *ctx, int on);
 
+/* ---- test / A-B hook (f16x3 datapath, per context): on = 1 (default) runs the 16x16-resolution tails of the nets - trunk_B1/B2 +
+ *      heads + attention 1 of the MTT nets, resblock_q3 .. conv_q2 of the QT nets - as ONE launch per net with the activations
+ *      resident in LDS (chain16.hip); on = 0 runs them launch per layer, as the other two datapaths always do.  Results are
+ *      BIT-IDENTICAL either way (tests/test_gpu_parity.py::test_fused_16x16_tails_are_bit_identical); only the launch count (84 -> 54
+ *      per luma pass) and the time differ.  Settles the calls in flight first. ---- */
+int pmp_debug_set_fusion(pmp_ctx *ctx, int on);
+
 /* ---- test hook (host only, no GPU needed): the f16x3 weight packing of one OIHW conv tensor (conv_f16x3.hip).
  *      Writes the power-of-two exponent k of the scale S = 2^k to *scale_exp and, if out != NULL, the packed stream
  *      [K-step][2 splits][cout_pad/16][64 lanes][8] of fp16 bit patterns (h0, h1 with h0 + h1 ~= S*w) to out.

@@ -69,6 +69,7 @@ SIGNATURES = {
     "pmp_ktime_get": (_I, [_VP, _I, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pmp_debug_set_conv_variant": (_I, [_I]),
     "pmp_debug_set_winograd": (_I, [_VP, _I]),
+    "pmp_debug_set_fusion": (_I, [_VP, _I]),
     "pmp_debug_pack_f16x3": (C.c_int64, [C.POINTER(C.c_float), _I, _I, _I, C.POINTER(C.c_uint16), C.c_int64, C.POINTER(C.c_int)]),
     "pmp_debug_conv_bench": (_I, [_VP, _I, _I, _I, _I, _I, _I, _I] + [C.POINTER(C.c_double)] * 4),
 }

@@ -181,6 +181,18 @@ struct Graph {
         return o;
     }
 
+    // chain16.hip: f16x3 only, and only with every block it names loaded in that format
+    bool fused16() const { return h2() && c->fuse16; }
+    bool c16rb(const std::string &name, Chain16RB &o, double &flops, int px)
+    {
+        auto it = w.rb.find(name);
+        if (it == w.rb.end() || !it->second.w0h) { if (rc == PMP_OK) rc = set_err(c, PMP_E_INVALID, "graph: no f16x3 weights for " + name); return false; }
+        const RBWeights &r = it->second;
+        o = Chain16RB{r.w0h, r.w2h, r.has_sc ? r.wsch : nullptr, std::ldexp(1.f, -r.k0), std::ldexp(1.f, -r.k2)};
+        flops += 2.0 * n * px * r.cout * (r.cin * r.k * r.k + r.cout * r.k * r.k + (r.has_sc ? r.cin : 0));
+        return true;
+    }
+
     void head(const Act &x, int slot, int layer, float *qt, float *bt, float *dire)
     {
         if (!live()) return;
@@ -200,6 +212,22 @@ int forward_q(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, con
     Act x2 = g.stem(luma, false, by, bu, bv, nullptr);
     Act x3 = g.rb(x2, "resblock_q1", luma);            // luma: + max_pool2d(2); chroma: no pool (:179)
     Act x4 = g.rb(x3, "resblock_q2", true);
+    if (g.fused16()) {   // q3 .. conv_q2 at 16x16 / 8x8: one launch, one workgroup per block, activations in LDS (chain16.hip)
+        Chain16QtArgs a{};
+        double flops = 0;
+        auto q6 = w.rb.find("resblock_q6");
+        if (q6 == w.rb.end() || !q6->second.direct) return set_err(c, PMP_E_INVALID, "graph: no weights for resblock_q6");
+        if (!g.c16rb("resblock_q3", a.q3, flops, 256) || !g.c16rb("resblock_q4", a.q4, flops, 256) || !g.c16rb("resblock_q5", a.q5, flops, 256)) return g.rc;
+        flops += 2.0 * n * 64 * 8 * (32 * 9 + 8 * 9 + 32) + 2.0 * n * 64 * 72.0;
+        a.x4 = x4.s(); a.x4_stride = x4.stride; a.qt = qt; a.N = n; a.sat = g.sat();
+        a.d_w0 = q6->second.w0; a.d_w2 = q6->second.w2; a.d_wsc = q6->second.wsc; a.head_w = w.head_w[0]; a.head_b = w.head_b[0];
+        if (g.live()) {
+            KScope ks(c, K_CONV_OTHER, flops);
+            g.check(launch_qt_tail16(c->stream, a), "qt_tail16");
+        }
+        g.release(x4);
+        return g.rc;
+    }
     Act x5 = g.rb(x4, "resblock_q3", false, nullptr, true);   // fp32: read by the multi-scale pool kernel
     Act x6 = g.alloc(128, 16, 16, g.x6());
     if (g.live()) {
@@ -227,26 +255,44 @@ int forward_msbd(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, 
     x = g.rb(x4, "trunk_M2.0", false, nullptr, false, false);   // x4 stays: attention 2 gates it (:150)
     for (int i = 1; i < 3; ++i) x = g.rb(x, "trunk_M2." + std::to_string(i));
     Act x5 = g.rb(x, "trunk_M2.3", true);
-    // branch B1 -> out0 (x5 stays: attention 1 gates it, :143)
-    Act b = g.rb(x5, "trunk_B1.0", false, nullptr, false, false);
-    b = g.rb(b, "trunk_B1.1");
-    b = g.rb(b, "trunk_B1.2", false, nullptr, true);
-    g.head(b, 0, 0, nullptr, bt, dire);
-    g.release(b);
-    // attention 1 gates x5 (:140-143), branch B2 -> out1 (accumulated in the head kernel, :146)
-    Act ai = g.alloc(16, 16, 16, g.x6());
-    if (g.live()) {
-        KScope ks(c, K_SMALL, 0.0);
-        g.check(launch_att_input(c->stream, qt, bt, dire, 0, ai.split ? nullptr : ai.p, n, 16, ai.split ? ai.s() : nullptr, ai.stride, g.fmt(), g.sat()), "att_input");
+    Act b{};
+    if (g.fused16()) {   // B1 + conv_B1, attention 1, B2 + conv_B2 at 16x16: one launch (chain16.hip)
+        Chain16MsbdArgs a{};
+        double flops = 2.0 * 2 * n * 256 * 72.0 * 2;
+        bool ok = true;
+        for (int i = 0; i < 3 && ok; ++i)
+            ok = g.c16rb("trunk_B1." + std::to_string(i), a.b1[i], flops, 256) && g.c16rb("trunk_B2." + std::to_string(i), a.b2[i], flops, 256);
+        for (int i = 0; i < 2 && ok; ++i) ok = g.c16rb("trunk_Att1." + std::to_string(i), a.att[i], flops, 256);
+        if (!ok) return g.rc;
+        a.x5 = x5.s(); a.x5_stride = x5.stride; a.qt = qt; a.bt = bt; a.dire = dire; a.N = n; a.sat = g.sat();
+        for (int i = 0; i < 2; ++i) { a.head_w[i] = w.head_w[i]; a.head_b[i] = w.head_b[i]; }
+        if (g.live()) {
+            KScope ks(c, K_CONV_OTHER, flops);
+            g.check(launch_msbd_branch16(c->stream, a), "msbd_branch16");
+        }
+        g.release(x5);
+    } else {
+        // branch B1 -> out0 (x5 stays: attention 1 gates it, :143)
+        b = g.rb(x5, "trunk_B1.0", false, nullptr, false, false);
+        b = g.rb(b, "trunk_B1.1");
+        b = g.rb(b, "trunk_B1.2", false, nullptr, true);
+        g.head(b, 0, 0, nullptr, bt, dire);
+        g.release(b);
+        // attention 1 gates x5 (:140-143), branch B2 -> out1 (accumulated in the head kernel, :146)
+        Act ai = g.alloc(16, 16, 16, g.x6());
+        if (g.live()) {
+            KScope ks(c, K_SMALL, 0.0);
+            g.check(launch_att_input(c->stream, qt, bt, dire, 0, ai.split ? nullptr : ai.p, n, 16, ai.split ? ai.s() : nullptr, ai.stride, g.fmt(), g.sat()), "att_input");
+        }
+        Act a1 = g.rb(ai, "trunk_Att1.0");
+        Act xb1 = g.rb(a1, "trunk_Att1.1", false, &x5);
+        g.release(x5);
+        b = g.rb(xb1, "trunk_B2.0");
+        b = g.rb(b, "trunk_B2.1");
+        b = g.rb(b, "trunk_B2.2", false, nullptr, true);
+        g.head(b, 1, 1, nullptr, bt, dire);
+        g.release(b);
     }
-    Act a1 = g.rb(ai, "trunk_Att1.0");
-    Act xb1 = g.rb(a1, "trunk_Att1.1", false, &x5);
-    g.release(x5);
-    b = g.rb(xb1, "trunk_B2.0");
-    b = g.rb(b, "trunk_B2.1");
-    b = g.rb(b, "trunk_B2.2", false, nullptr, true);
-    g.head(b, 1, 1, nullptr, bt, dire);
-    g.release(b);
     // attention 2 gates x4 at 32x32 (:147-150), branch B3 -> pool -> out2 (:151-153)
     Act aj = g.alloc(16, 32, 32, g.x6());
     if (g.live()) {

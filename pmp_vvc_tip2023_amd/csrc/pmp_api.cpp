@@ -720,6 +720,15 @@ int pmp_debug_set_conv_variant(int variant)
 #endif
 }
 
+int pmp_debug_set_fusion(pmp_ctx *c, int on)
+{
+    CHECK_CTX(c);
+    const int rc = settle(c);
+    if (rc != PMP_OK) return rc;
+    c->fuse16 = on ? 1 : 0;
+    return PMP_OK;
+}
+
 int pmp_debug_set_winograd(pmp_ctx *c, int on)
 {
     CHECK_CTX(c);

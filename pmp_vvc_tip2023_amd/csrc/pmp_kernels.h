@@ -68,6 +68,33 @@ hipError_t launch_conv_h2_wx(hipStream_t s, const ConvX6Args &a);
 hipError_t launch_f32_to_split2(hipStream_t s, const float *x, unsigned short *out, size_t n, size_t plane_stride, unsigned *sat = nullptr);
 hipError_t launch_split2_to_f32(hipStream_t s, const unsigned short *x, float *out, size_t n, size_t plane_stride);
 
+// ------------------------------------------------------------------------------------------------ 16x16 tails, one workgroup per block
+// chain16.hip (f16x3 datapath): the layers of a net that run at 16x16 resolution - where a block is a single tile - as ONE launch with
+// every activation resident in LDS; bit-identical to the launch-per-layer path.  Weights: a ResidualBlock's pack_h2 streams
+// (RBWeights::w0h / w2h / wsch) with 1/S of its two passes (s0 = 2^-k0, s2 = 2^-k2).
+struct Chain16RB { const unsigned short *w0, *w2, *wsc; float s0, s2; };
+// MTT nets: trunk_B1 + conv_B1 -> out0; cat[up2(q), out0] -> trunk_Att1, x x5 -> trunk_B2 + conv_B2 -> out1 (accumulated)
+struct Chain16MsbdArgs {
+    const unsigned short *x5; size_t x5_stride;     // [N][4][16][16][16] split-2
+    const float *qt; float *bt, *dire;              // raw QT logits [N][64]; outputs [N][3][256], layers 0 and 1
+    Chain16RB b1[3], att[2], b2[3];
+    const float *head_w[2], *head_b[2];             // conv_B1, conv_B2: [9][8][2] + [2]
+    unsigned *sat;
+    int N;
+};
+hipError_t launch_msbd_branch16(hipStream_t s, const Chain16MsbdArgs &a);
+// QT nets: resblock_q3 -> multi-scale pool -> resblock_q4 -> resblock_q5 + max_pool2d(2) -> resblock_q6 (8x8, fp32 direct) -> conv_q2
+struct Chain16QtArgs {
+    const unsigned short *x4; size_t x4_stride;     // [N][4][16][16][16] split-2: resblock_q2's pooled output
+    float *qt;                                      // [N][64]
+    Chain16RB q3, q4, q5;
+    const float *d_w0, *d_w2, *d_wsc;               // resblock_q6, plain fp32 packing (pack_plain)
+    const float *head_w, *head_b;                   // conv_q2: [9][8][1] + [1]
+    unsigned *sat;
+    int N;
+};
+hipError_t launch_qt_tail16(hipStream_t s, const Chain16QtArgs &a);
+
 // ------------------------------------------------------------------------------------------------ stems
 // First layers straight from the u8 blocks (Model_QBD.py:79-80, :130-135, :177-178, :228-233).
 // luma: block_y u8[N][68][68];  chroma: + block_u/v u8[N][34][34], plane 0 = 2x2 max-pool of block_y

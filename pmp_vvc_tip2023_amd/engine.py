@@ -73,6 +73,10 @@ class Engine:
         fp32-equivalent - or 'fp32' (exact fp32 MFMA)."""
         self._ck(self.lib.pmp_set_precision(self.h, {"fp32": 0, "f32": 0, "bf16x6": 1, "f16x3": 2}[mode]))
 
+    def set_fusion(self, on):
+        """f16x3: the 16x16-resolution tails as one launch per net (default) or launch per layer - bit-identical results (include/pmp.h)."""
+        self._ck(self.lib.pmp_debug_set_fusion(self.h, 1 if on else 0))
+
     def get_precision(self):
         return {0: "fp32", 1: "bf16x6", 2: "f16x3"}[self.lib.pmp_get_precision(self.h)]
 

@@ -398,6 +398,62 @@ def test_device_calls_do_not_stall_the_host_and_the_guard_still_repairs(g1, orac
         e2.close()
 
 
+@pytest.mark.parametrize("comp", ["Luma", "Chroma"])
+def test_fused_16x16_tails_are_bit_identical(comp):
+    """chain16.hip: on the f16x3 datapath the 16x16-resolution tails of the nets (MTT: trunk_B1/B2 + heads + attention 1; QT: resblock_q3 ..
+    conv_q2) run as one launch per net with the activations in LDS.  Same weight streams, same K-step order, same epilogue arithmetic:
+    the logits must equal the launch-per-layer path's BIT FOR BIT - on the golden blocks, on fresh ones (all-0 and all-255 included), at
+    every QP, with a ragged chunk, and through the range guard's flag (the fused kernels raise it like the layer kernels do)."""
+    from pmp_vvc_tip2023_amd import engine, synth
+    g1 = golden("g1_qt.npz")
+    y, u, v = synth.recipe_r_blocks(150, 4242)
+    y[0] = 0; u[0] = 0; v[0] = 0
+    y[1] = 255; u[1] = 255; v[1] = 255
+    y[2:18] = g1["block_y"]; u[2:18] = g1["block_u"]; v[2:18] = g1["block_v"]
+    e = engine.Engine(0, allow_synthetic_mtt=True)
+    try:
+        e.set_precision("f16x3")
+        for qp in (22, 27, 32, 37):
+            e.set_fusion(True)
+            a = e.inference_pre_QBD(comp, qp, y, u, v)
+            e.set_fusion(False)
+            b = e.inference_pre_QBD(comp, qp, y, u, v)
+            for nm, p, q in zip(("qt", "bt", "dire"), a, b):
+                assert np.array_equal(p, q), "%s QP%d %s: fused and per-layer paths differ by %g" % (comp, qp, nm, np.abs(p - q).max())
+            assert np.isfinite(a[0]).all() and np.abs(a[1]).max() > 0.1      # not a comparison of two empty results
+        e.set_fusion(True)
+        e.set_chunk(37)
+        try:
+            c = e.inference_pre_QBD(comp, 37, y, u, v)
+        finally:
+            e.set_chunk(4096)
+        assert all(np.array_equal(p, q) for p, q in zip(a, c))
+        # launches per pass: the fused path saves the ~30 launches of the tails
+        names = [e.lib.pmp_ktime_name(k).decode() for k in range(e.lib.pmp_ktime_classes())]
+        counts = {}
+        for on in (True, False):
+            e.set_fusion(on)
+            e.ktime_enable(0xFFFF)
+            e.inference_pre_QBD(comp, 22, y[:8], u[:8], v[:8])
+            counts[on] = sum(int(ln) for ln, _, _ in e.ktime().values())
+            e.ktime_enable(0)
+        assert counts[False] - counts[True] >= 25 and counts[True] <= 45, counts      # 67 -> 40 launches per (QT + MTT) pass
+        assert len(names) >= 6
+        if comp == "Luma":          # range stress: the clamp fires inside the fused kernels too - same clamped bits, same raised flag
+            e.load("Luma", 22)
+            e.load_pretrain_model("Luma_MSBD", 22, _range_stress_weights())
+            e.set_saturation_policy("ignore")
+            got = {}
+            for on in (True, False):
+                e.set_fusion(on)
+                e.clear_saturation()
+                got[on] = e.inference_pre_QBD("Luma", 22, y[:6])
+                assert e.saturated()
+            assert all(np.array_equal(p, q) for p, q in zip(got[True], got[False]))
+    finally:
+        e.close()
+
+
 def test_product_library_ships_no_winograd_form():
     """The Winograd-x form of the 3x3 64->64 convolutions (conv_f16x3_wx.hip) did not beat the direct kernels, so - like every other form
     that lost its A/B - it is built into the measurement library only: the product library accepts "off" and refuses "on".  Its parity
