@@ -17,10 +17,21 @@
 // the last pair with zero weights (3x3: 10 % padding, 5x5: 4 %).
 #include <type_traits>
 
-#include "pmp_kernels.h"
-#include "split3.h"
+#include "abl_kernels.h"
+#include "../split3.h"
 
 namespace pmp {
+
+// In-kernel stamps (diagnostic builds only, ABL bit 128): shader-clock ticks of wave 0 at phase boundaries, written to a
+// debug buffer nothing else reads (cdna guide, 'In-kernel stamps').
+__device__ __forceinline__ unsigned long long stamp_now()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
 
 // Per-lane staging plan, computed ONCE per workgroup: element offset (inside one 16-channel group, split plane
 // included) of each 16-B piece this thread copies, and a validity mask for the zero padding.  The per-group work is then
@@ -74,12 +85,14 @@ __device__ __forceinline__ void x6_stage_store(const StagePlan<KH, KW> &p, u32x4
     }
 }
 
-template <int KH, int KW, int NT>
+template <int KH, int KW, int NT, int ABL = 0>
 __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__ x, size_t plane_stride,
                                               const unsigned short *__restrict__ wpk, int C, int H, int W, int n, int ty,
-                                              int tx, u32x4 *lds, f32x4 (&acc)[4][NT])
+                                              int tx, u32x4 *lds, f32x4 (&acc)[4][NT], unsigned long long *dbg = nullptr)
 {
     typedef GeoX<KH, KW> G;
+    unsigned long long t_pro = 0, t_k = 0, t_s = 0, t_w = 0, t_b = 0, tmark = 0;   // diagnostic accumulators (ABL & 128)
+    if (ABL & 128) tmark = stamp_now();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, xl = lane & 15, g = lane >> 4;
     const int CB = C >> 4;
     const size_t grp_sz = (size_t)H * W * 16;
@@ -91,6 +104,7 @@ __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__
     x6_stage_load<KH, KW>(plan, grp0, r);
     x6_stage_store<KH, KW>(plan, lds, r);
     __syncthreads();
+    if (ABL & 128) { const unsigned long long t = stamp_now(); t_pro = t - tmark; tmark = t; }
     // ---- K-step schedule -------------------------------------------------------------------------------------
     // Weight fragments live in ONE register set that is refilled in place, split by split, as soon as its last MFMA
     // of the K-step has been issued: w2 is used once (with x0), w1 twice, w0 three times, so the products are ordered
@@ -121,7 +135,7 @@ __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__
         constexpr int NK = MODE == 0 ? G::NKS : (MODE == 1 ? (G::TAPS - 1) / 2 : (G::TAPS - 1) / 2 + 1);
         constexpr int PER = (G::NLD + (NK > 0 ? NK : 1) - 1) / (NK > 0 ? NK : 1);   // staging loads issued per K-step
         const bool more = cb + 1 < CB;
-        const unsigned short *nxt_grp = grp0 + (size_t)min(cb + 1, CB - 1) * grp_sz;   // clamped: loads stay unconditional
+        const unsigned short *nxt_grp = ((ABL & 32) ? x : grp0) + (size_t)min(cb + 1, CB - 1) * grp_sz;   // clamped: loads stay unconditional
         const char *buf = reinterpret_cast<const char *>(lds + (cb & 1) * G::PIECES);
         const char *prv = reinterpret_cast<const char *>(lds + ((cb + 1) & 1) * G::PIECES);
         // per-lane address of this lane's tap of K-step ks (lanes g < 2: first tap of the pair, g >= 2: second)
@@ -138,7 +152,7 @@ __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__
         };
         bf16x8 xa[4], xb[4], x1[4], x2[4];   // x0 fragments alternate between xa (even K-steps) and xb (odd)
         if (NK == 0) {   // 1x1 source, even group: nothing to compute yet, only fetch the partner group
-            x6_stage_load<KH, KW>(plan, nxt_grp, r);
+            if (!(ABL & 1)) x6_stage_load<KH, KW>(plan, nxt_grp, r);
         } else {
             const char *p0 = xaddr(0);
 #pragma unroll
@@ -152,21 +166,23 @@ __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__
             const bf16x8 *wk = wl + (size_t)min(stream, last) * (3 * NT * 64);
             bf16x8 (&x0)[4] = (ks & 1) ? xb : xa;
             bf16x8 (&x0n)[4] = (ks & 1) ? xa : xb;
-            {
+            if (!(ABL & 4) || ks == 0) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m) x1[m] = *reinterpret_cast<const bf16x8 *>(px + G::PLANE * 16 + m * G::TW * 32);
 #pragma unroll
                 for (int m = 0; m < 4; ++m) x2[m] = *reinterpret_cast<const bf16x8 *>(px + 2 * G::PLANE * 16 + m * G::TW * 32);
             }
-            x6_stage_load<KH, KW>(plan, nxt_grp, r, ks * PER, (ks + 1) * PER);
+            if (!(ABL & 1)) x6_stage_load<KH, KW>(plan, nxt_grp, r, ks * PER, (ks + 1) * PER);
             __builtin_amdgcn_sched_barrier(0);
             // phase A
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[nt], x0[m], acc[m][nt], 0, 0, 0);
+            if (!(ABL & 2)) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) w2[nt] = wk[(2 * NT + nt) * 64];
+                for (int nt = 0; nt < NT; ++nt) w2[nt] = wk[(2 * NT + nt) * 64];
+            }
             __builtin_amdgcn_sched_barrier(0);
             // phase B
 #pragma unroll
@@ -176,9 +192,11 @@ __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__
                     acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[nt], x0[m], acc[m][nt], 0, 0, 0);
                     acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[nt], x1[m], acc[m][nt], 0, 0, 0);
                 }
+            if (!(ABL & 2)) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) w1[nt] = wk[(1 * NT + nt) * 64];
-            if (ks + 1 < NK) {
+                for (int nt = 0; nt < NT; ++nt) w1[nt] = wk[(1 * NT + nt) * 64];
+            }
+            if (ks + 1 < NK && !(ABL & 4)) {
                 const char *pn = xaddr(ks + 1);
 #pragma unroll
                 for (int m = 0; m < 4; ++m) x0n[m] = *reinterpret_cast<const bf16x8 *>(pn + m * G::TW * 32);
@@ -193,16 +211,28 @@ __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__
                     acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[nt], x1[m], acc[m][nt], 0, 0, 0);
                     acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[nt], x2[m], acc[m][nt], 0, 0, 0);
                 }
+            if (!(ABL & 2)) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) w0[nt] = wk[(0 * NT + nt) * 64];
+                for (int nt = 0; nt < NT; ++nt) w0[nt] = wk[(0 * NT + nt) * 64];
+            }
             __builtin_amdgcn_sched_barrier(0);
             // The cross-group K-step is the only one that reads the OTHER halo buffer; every wave must be past it before any
             // wave overwrites that buffer at the end of this group (the waves of a workgroup are only loosely in step).
             if (MODE == 2 && ks == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
+        if (ABL & 128) { const unsigned long long t = stamp_now(); t_k += t - tmark; tmark = t; }
         // the partner buffer is only overwritten here, after the last K-step that may read the previous group from it
-        if (more) x6_stage_store<KH, KW>(plan, lds + ((cb + 1) & 1) * G::PIECES, r);
-        __syncthreads();
+        if ((ABL & 128) && more) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long t = stamp_now(); t_w += t - tmark; tmark = t; }
+        if (more && !(ABL & 1)) {
+            if (ABL & 256) {   // timing-only: keep the loads alive, skip the LDS stores
+#pragma unroll
+                for (int k = 0; k < G::NLD; ++k) asm volatile("" ::"v"(r[k]));
+            } else
+                x6_stage_store<KH, KW>(plan, lds + ((cb + 1) & 1) * G::PIECES, r);
+        }
+        if (ABL & 128) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t = stamp_now(); t_s += t - tmark; tmark = t; }
+        if (!(ABL & 16)) __syncthreads();
+        if (ABL & 128) { const unsigned long long t = stamp_now(); t_b += t - tmark; tmark = t; }
     };
 
     if (paired) {
@@ -213,9 +243,10 @@ __device__ __forceinline__ void x6_accumulate(const unsigned short *__restrict__
     } else {
         for (int cb = 0; cb < CB; ++cb) group(std::integral_constant<int, 0>{}, cb);
     }
+    if ((ABL & 128) && dbg && threadIdx.x == 0) { dbg[0] = t_pro; dbg[1] = t_k; dbg[2] = t_s; dbg[6] = t_w; dbg[7] = t_b; }
 }
 
-template <int KH, int KW, int NT>
+template <int KH, int KW, int NT, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_x6_kernel(ConvX6Args a)
 {
     typedef GeoX<KH, KW> G;
@@ -230,11 +261,22 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(ConvX6Args a)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    x6_accumulate<KH, KW, NT>(a.x, a.x_stride, a.w, a.Cin, a.H, a.W, n, ty, tx, lds, acc);
+    const unsigned long long t_begin = (ABL & 128) ? stamp_now() : 0;
+    x6_accumulate<KH, KW, NT, ABL>(a.x, a.x_stride, a.w, a.Cin, a.H, a.W, n, ty, tx, lds, acc, a.abl.dbg ? a.abl.dbg + (size_t)blockIdx.x * 8 : nullptr);
+    const unsigned long long t_acc = (ABL & 128) ? stamp_now() : 0;
     if (a.x_sc) x6_accumulate<1, 1, NT>(a.x_sc, a.sc_stride, a.w_sc, a.Csc, a.H, a.W, n, ty, tx, lds, acc);
 
     const int H = a.H, W = a.W;
     const size_t grp = (size_t)H * W * 16;
+    if (ABL & 8) {  // timing-only build: skip the epilogue but keep the accumulators live
+        float sacc = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) sacc += acc[m][nt].x + acc[m][nt].y + acc[m][nt].z + acc[m][nt].w;
+        if (sacc == 123.456f) a.out[0] = 1;
+        return;
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -273,6 +315,12 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(ConvX6Args a)
             }
         }
     }
+    if ((ABL & 128) && a.abl.dbg && threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // include the store acknowledgements in the epilogue span
+        const unsigned long long t_end = stamp_now();
+        unsigned long long *d = a.abl.dbg + (size_t)blockIdx.x * 8;
+        d[3] = t_acc - t_begin; d[4] = t_end - t_acc; d[5] = t_begin;
+    }
 }
 
 template <int KH, int KW>
@@ -282,7 +330,28 @@ static hipError_t launch_x6(hipStream_t s, const ConvX6Args &a)
     switch (a.Cout >> 4) {
     case 1: hipLaunchKernelGGL((conv_x6_kernel<KH, KW, 1>), dim3(grid), dim3(256), 0, s, a); break;
     case 2: hipLaunchKernelGGL((conv_x6_kernel<KH, KW, 2>), dim3(grid), dim3(256), 0, s, a); break;
-    case 4: hipLaunchKernelGGL((conv_x6_kernel<KH, KW, 4>), dim3(grid), dim3(256), 0, s, a); break;
+    case 4:
+#ifdef PMP_ABLATION   // timing-only builds (wrong results): only in libpmp_hip_abl.so, never in the product library
+        if (KH == 3 && g_conv_variant >= 10) {  // timing-only ablation builds (tools/conv_x6_bench.py)
+            switch (g_conv_variant - 10) {
+            case 1: hipLaunchKernelGGL((conv_x6_kernel<3, 3, 4, 1>), dim3(grid), dim3(256), 0, s, a); break;
+            case 2: hipLaunchKernelGGL((conv_x6_kernel<3, 3, 4, 2>), dim3(grid), dim3(256), 0, s, a); break;
+            case 4: hipLaunchKernelGGL((conv_x6_kernel<3, 3, 4, 4>), dim3(grid), dim3(256), 0, s, a); break;
+            case 8: hipLaunchKernelGGL((conv_x6_kernel<3, 3, 4, 8>), dim3(grid), dim3(256), 0, s, a); break;
+            case 15: hipLaunchKernelGGL((conv_x6_kernel<3, 3, 4, 15>), dim3(grid), dim3(256), 0, s, a); break;
+            case 16: hipLaunchKernelGGL((conv_x6_kernel<3, 3, 4, 16>), dim3(grid), dim3(256), 0, s, a); break;
+            case 31: hipLaunchKernelGGL((conv_x6_kernel<3, 3, 4, 31>), dim3(grid), dim3(256), 0, s, a); break;
+            case 32: hipLaunchKernelGGL((conv_x6_kernel<3, 3, 4, 32>), dim3(grid), dim3(256), 0, s, a); break;
+            case 40: hipLaunchKernelGGL((conv_x6_kernel<3, 3, 4, 40>), dim3(grid), dim3(256), 0, s, a); break;
+            case 128: hipLaunchKernelGGL((conv_x6_kernel<3, 3, 4, 128>), dim3(grid), dim3(256), 0, s, a); break;
+            case 200: hipLaunchKernelGGL((conv_x6_kernel<3, 3, 4, 256>), dim3(grid), dim3(256), 0, s, a); break;
+            default: hipLaunchKernelGGL((conv_x6_kernel<KH, KW, 4>), dim3(grid), dim3(256), 0, s, a); break;
+            }
+            break;
+        }
+#endif
+            hipLaunchKernelGGL((conv_x6_kernel<KH, KW, 4>), dim3(grid), dim3(256), 0, s, a);
+        break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -35,8 +35,8 @@
 // Synchronisation: groups 0, 1 -> buffers 0, 1 in the prologue; K-steps 0..8 (pair 0; r = 4 is the cross step: tap 8 of the even
 // group for lanes g < 2, tap 8 of the odd group for lanes g >= 2); barrier, burst refill with groups 2, 3, vmcnt(0), barrier;
 // K-steps 9..17.
-#include "pmp_kernels.h"
-#include "split3.h"
+#include "abl_kernels.h"
+#include "../split3.h"
 
 namespace pmp {
 
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_t32_kernel(ConvX6Args a)
         const int gy = ty * 32 + row - 1, gx = tx * 16 + col - 1;
         const bool in_image = i < T32_PIECES && gy >= 0 && gy < H && gx >= 0 && gx < W;   // else: zero padding, or a dummy piece
         const size_t off = (size_t)sp * a.x_stride + (size_t)grp * grp_sz + ((size_t)(gy * W + gx) * 16 + half * 8);
-        const void *src = in_image ? (const void *)(xg0 + off) : a.zeros;
+        const void *src = in_image ? (const void *)(xg0 + off) : a.abl.zeros;
         t32_dma16(src, lds_base + (unsigned)((buf * T32_BUF + (4 * k + wave) * 64) * 16));
     };
 
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_t32_kernel(ConvX6Args a)
 bool conv_h2_t32_applicable(const ConvX6Args &a)
 {
     return a.KH == 3 && a.KW == 3 && a.Cin == 64 && a.Cout == 64 && !a.x_sc && !a.gate && !a.out_f32 && a.out && (a.H & 31) == 0 &&
-           (a.W & 15) == 0 && a.zeros != nullptr && a.N > 0;
+           (a.W & 15) == 0 && a.abl.zeros != nullptr && a.N > 0;
 }
 
 hipError_t launch_conv_h2_t32(hipStream_t s, const ConvX6Args &a)

@@ -20,8 +20,8 @@
 #include <cstdio>
 #include <vector>
 
-#include "pmp_kernels.h"
-#include "split3.h"
+#include "abl_kernels.h"
+#include "../split3.h"
 
 namespace pmp {
 
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_wx_kernel(ConvX6Args a)
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds;
     auto stage_load = [&](int g) __attribute__((always_inline)) {
         if (((ABL & 1) && g > 1) || (ABL & 8)) return;
-        wx_load(itA, grp0 + (size_t)g * grp_sz, a.x_stride, a.zeros, rA);
+        wx_load(itA, grp0 + (size_t)g * grp_sz, a.x_stride, a.abl.zeros, rA);
     };
     auto stage_store = [&](int g) __attribute__((always_inline)) {
         if (((ABL & 1) && g > 1) || (ABL & 8)) return;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_wx_kernel(ConvX6Args a)
             const int gy = ty * 16 + 15 + rowsel, gx = tx * 16 - 1 + px;
             const bool in = gy < H && gx >= 0 && gx < W;
             const unsigned short *src = grp0 + (size_t)g * grp_sz + (size_t)plane * a.x_stride + ((size_t)min(gy, H - 1) * W + min(max(gx, 0), W - 1)) * 16 + half * 8;
-            wx_dma16(in ? (const void *)src : a.zeros, __builtin_amdgcn_readfirstlane(lds_base + 2 * WX_BUFB + (g & 1) * WX_RAWB + wave * 1024));
+            wx_dma16(in ? (const void *)src : a.abl.zeros, __builtin_amdgcn_readfirstlane(lds_base + 2 * WX_BUFB + (g & 1) * WX_RAWB + wave * 1024));
         }
     };
     auto transform_B = [&](int g) __attribute__((always_inline)) {  // RAW[g & 1] -> V rows 16, 17 of buffer g & 1, by half of wave g & 3
@@ -360,24 +360,24 @@ __global__ __launch_bounds__(256, 2) void conv_h2_wx_kernel(ConvX6Args a)
         }
     }
     sat_report(a.sat, omax);
-    if ((ABL & 128) && a.dbg && tid == 0) {
+    if ((ABL & 128) && a.abl.dbg && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // include the store acknowledgements in the epilogue span
         ts[nts++] = wx_stamp();                             // 11: epilogue done
-        for (int i = 0; i < 12; ++i) a.dbg[(size_t)blockIdx.x * 12 + i] = ts[i];
+        for (int i = 0; i < 12; ++i) a.abl.dbg[(size_t)blockIdx.x * 12 + i] = ts[i];
     }
 }
 
 bool conv_h2_wx_applicable(const ConvX6Args &a)
 {
-    return a.w_wx && a.KH == 3 && a.KW == 3 && a.Cin == 64 && a.Cout == 64 && !a.x_sc && !a.gate && !a.out_f32 && !a.pool && a.out &&
+    return a.abl.w_wx && a.KH == 3 && a.KW == 3 && a.Cin == 64 && a.Cout == 64 && !a.x_sc && !a.gate && !a.out_f32 && !a.pool && a.out &&
            !(a.H & 15) && !(a.W & 15) && a.N > 0;
 }
 
 hipError_t launch_conv_h2_wx(hipStream_t s, const ConvX6Args &a_in)
 {
     ConvX6Args a = a_in;
-    a.w = a.w_wx;
-    a.out_scale = a.wx_out_scale;
+    a.w = a.abl.w_wx;
+    a.out_scale = a.abl.wx_out_scale;
     const int grid = a.N * (a.H >> 4) * (a.W >> 4);
 #ifdef PMP_ABLATION
     { static bool once = false; if (!once) { once = true; int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_h2_wx_kernel<0>, 256, 0);
@@ -387,7 +387,7 @@ hipError_t launch_conv_h2_wx(hipStream_t s, const ConvX6Args &a_in)
         unsigned long long *ddbg = nullptr;
         if (hipMalloc((void **)&ddbg, (size_t)grid * 12 * 8) != hipSuccess) return hipErrorOutOfMemory;
         hipMemsetAsync(ddbg, 0, (size_t)grid * 12 * 8, s);
-        a.dbg = ddbg;
+        a.abl.dbg = ddbg;
         hipLaunchKernelGGL(conv_h2_wx_kernel<128>, dim3(grid), dim3(256), 0, s, a);
         hipStreamSynchronize(s);
         static int reported = 0;

@@ -20,7 +20,7 @@
 // LDS: the (16+KH-1) x (16+KW-1) halo tile of ONE 16-channel group (64 B per pixel), XOR-swizzled so the
 // ds_read_b128 of 16 consecutive pixels is conflict-free in every b128 lane group (slot ^= 2*((pix>>2)&1)).
 // Weights never touch LDS: they are pre-packed in fragment order and streamed from L2 with 16-B lane loads.
-#include "pmp_kernels.h"
+#include "abl_kernels.h"
 
 namespace pmp {
 
@@ -114,6 +114,56 @@ __device__ __forceinline__ void stage_store(f32x4 *lds, const f32x4 (&r)[Geo<KH,
     }
 }
 
+template <int KH, int KW, int NT, int BUFSZ>
+__device__ __forceinline__ void accumulate_pipe(const float *__restrict__ x, const float *__restrict__ wpk, int C, int H,
+                                                int W, int n, int ty, int tx, f32x4 *lds, f32x4 (&acc)[4][NT])
+{
+    constexpr int TW = Geo<KH, KW>::TW, TAPS = KH * KW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, xl = lane & 15, g = lane >> 4;
+    const int CB = C >> 4;
+    const size_t plane_sz = (size_t)H * W * 16;
+    const float *plane = x + (size_t)n * CB * plane_sz;
+    f32x4 r[Geo<KH, KW>::NLD];
+    __syncthreads();  // LDS may still be read by a previous source
+    stage_load<KH, KW>(plane, H, W, ty, tx, r);
+    stage_store<KH, KW>(lds, r, H, W, ty, tx);
+    const f32x4 *wl = reinterpret_cast<const f32x4 *>(wpk) + lane;
+    const int last = CB * TAPS - 1;
+    f32x4 wn[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wn[nt] = wl[nt * 64];
+    __syncthreads();
+    int stream = 0;  // index of the (channel group, tap) whose weights sit in wn
+    for (int cb = 0; cb < CB; ++cb) {
+        if (cb + 1 < CB) stage_load<KH, KW>(plane + (size_t)(cb + 1) * plane_sz, H, W, ty, tx, r);
+        const f32x4 *buf = lds + (cb & 1) * BUFSZ;
+        int dy = 0, dx = 0;
+#pragma unroll 1
+        for (int tap = 0; tap < TAPS; ++tap) {
+            f32x4 wf[NT];
+            stream = min(stream + 1, last);
+            const f32x4 *wp = wl + (size_t)stream * (NT * 64);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { wf[nt] = wn[nt]; wn[nt] = wp[nt * 64]; }
+            f32x4 a[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) a[m] = buf[lds_slot(wave * 4 + m + dy, xl + dx, g, TW)];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt].x, a[m].x, acc[m][nt], 0, 0, 0);
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt].y, a[m].y, acc[m][nt], 0, 0, 0);
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt].z, a[m].z, acc[m][nt], 0, 0, 0);
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt].w, a[m].w, acc[m][nt], 0, 0, 0);
+                }
+            if (++dx == KW) { dx = 0; ++dy; }
+        }
+        if (cb + 1 < CB) stage_store<KH, KW>(lds + ((cb + 1) & 1) * BUFSZ, r, H, W, ty, tx);
+        __syncthreads();
+    }
+}
+
 // ---- fully software-pipelined variant (variant 2) --------------------------------------------------------------
 // Unrolled taps with a scheduling fence between them, so every s_waitcnt is an exact count:
 //   * weight fragments are requested TWO taps ahead (3-deep register ring),
@@ -187,7 +237,7 @@ template <int KH, int KW, int NT, int PIPE, int OCC>
 __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvMfmaArgs a)
 {
     constexpr int BUFSZ = Geo<KH, KW>::PIECES;
-    __shared__ f32x4 lds[BUFSZ * (PIPE ? 2 : 1)];  // PIPE: 0 plain (1x1), 2 fully pipelined (the intermediate form 1 is in abl/)
+    __shared__ f32x4 lds[BUFSZ * (PIPE ? 2 : 1)];  // PIPE: 0 plain, 1 pipelined, 2 fully pipelined
     const int tiles_x = a.W >> 4, tiles = tiles_x * (a.H >> 4);
     const int n = blockIdx.x / tiles, t = blockIdx.x - n * tiles, ty = t / tiles_x, tx = t - ty * tiles_x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, xl = lane & 15, g = lane >> 4;
@@ -201,6 +251,9 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvMfmaArgs a)
     if constexpr (PIPE == 2) {
         accumulate_pipe2<KH, KW, NT, BUFSZ>(a.x, a.w, a.Cin, a.H, a.W, n, ty, tx, lds, acc);
         if (a.x_sc) accumulate_pipe2<1, 1, NT, BUFSZ>(a.x_sc, a.w_sc, a.Csc, a.H, a.W, n, ty, tx, lds, acc);
+    } else if constexpr (PIPE == 1) {
+        accumulate_pipe<KH, KW, NT, BUFSZ>(a.x, a.w, a.Cin, a.H, a.W, n, ty, tx, lds, acc);
+        if (a.x_sc) accumulate_pipe<1, 1, NT, BUFSZ>(a.x_sc, a.w_sc, a.Csc, a.H, a.W, n, ty, tx, lds, acc);
     } else {
         accumulate<KH, KW, NT>(a.x, a.w, a.Cin, a.H, a.W, n, ty, tx, lds, acc);
         if (a.x_sc) accumulate<1, 1, NT>(a.x_sc, a.w_sc, a.Csc, a.H, a.W, n, ty, tx, lds, acc);
@@ -250,6 +303,9 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvMfmaArgs a)
     }
 }
 
+#ifdef PMP_ABLATION
+int g_conv_variant = 2;  // measurement library only: 0: un-pipelined; 1: pipelined, 3 waves/SIMD; 2: the shipped form (A/B measurements)
+#endif
 
 template <int KH, int KW, int PIPE, int OCC>
 static hipError_t launch_k(hipStream_t s, const ConvMfmaArgs &a)
@@ -269,6 +325,13 @@ hipError_t launch_conv_mfma(hipStream_t s, const ConvMfmaArgs &a)
     if ((a.H & 15) || (a.W & 15) || (a.Cin & 15) || (a.Cout & 15) || (a.x_sc && (a.Csc & 15)) || a.N <= 0)
         return hipErrorInvalidValue;
     if (a.pool && a.gate) return hipErrorInvalidValue;
+#ifdef PMP_ABLATION
+    const int v = g_conv_variant > 2 ? 2 : g_conv_variant;
+    if (v < 2) {
+        if (a.KH == 3 && a.KW == 3) return v == 0 ? launch_k<3, 3, 0, 1>(s, a) : launch_k<3, 3, 1, 3>(s, a);
+        if (a.KH == 5 && a.KW == 5) return v == 0 ? launch_k<5, 5, 0, 1>(s, a) : launch_k<5, 5, 1, 3>(s, a);
+    }
+#endif
     // shipped form: fully software-pipelined, two waves per SIMD
     if (a.KH == 3 && a.KW == 3) return launch_k<3, 3, 2, 2>(s, a);
     if (a.KH == 5 && a.KW == 5) return launch_k<5, 5, 2, 2>(s, a);

@@ -50,7 +50,7 @@ extern "C" int pmp_abl_rbfuse_bench(pmp_ctx *c, int n, int h, int w, int iters, 
         launch_f32_to_split2(c->stream, dx, dxs, ne, ne);
         ConvX6Args a1{}, a2{};
         a1.x = dxs; a1.x_stride = ne; a1.w = dw1; a1.out = dt; a1.out_stride = ne; a1.N = n; a1.H = h; a1.W = w; a1.Cin = 64; a1.Cout = 64; a1.KH = a1.KW = 3;
-        a1.relu = 1; a1.out_scale = std::ldexp(1.f, -k1); a1.sat = c->d_sat; a1.zeros = c->d_sat + 16;
+        a1.relu = 1; a1.out_scale = std::ldexp(1.f, -k1); a1.sat = c->d_sat; a1.abl.zeros = c->d_sat + 16;
         a2 = a1;
         a2.x = dt; a2.w = dw2; a2.out = dy; a2.res = dxs; a2.res_stride = ne; a2.out_scale = std::ldexp(1.f, -k2);
         RbFuseArgs f{dxs, ne, dw1, dw2, std::ldexp(1.f, -k1), std::ldexp(1.f, -k2), dy2, ne, n, h, w, c->d_sat};

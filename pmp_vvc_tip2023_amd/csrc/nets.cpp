@@ -94,10 +94,8 @@ struct Graph {
             ConvX6Args a{};
             a.x = x.s(); a.x_stride = x.stride;
             if (h2()) {
-                a.w = second ? r.w2h : r.w0h; a.out_scale = std::ldexp(1.f, -(second ? r.k2 : r.k0)); a.sat = sat(); a.zeros = c->d_sat + 16;
-#ifdef PMP_ABLATION
-                if (c->winograd && r.w0w) { a.w_wx = second ? r.w2w : r.w0w; a.wx_out_scale = std::ldexp(1.f, -(second ? r.k2w : r.k0w)); }
-#endif
+                a.w = second ? r.w2h : r.w0h; a.out_scale = std::ldexp(1.f, -(second ? r.k2 : r.k0)); a.sat = sat();
+                abl_conv_args(c, r, second, a);
             }
             else a.w = second ? r.w2x : r.w0x;
             if (sc_src) { a.x_sc = sc_src->s(); a.sc_stride = sc_src->stride; a.w_sc = h2() ? r.wsch : r.wscx; a.Csc = sc_src->C; }

@@ -74,6 +74,9 @@ static inline void split8(const float *v, unsigned short *h0, unsigned short *h1
 static inline void split8(const float *v, unsigned short *h0, unsigned short *h1) { split8_generic(v, h0, h1); }
 #endif
 
+void h2_split8(const float *v, unsigned short *h0, unsigned short *h1) { split8(v, h0, h1); }
+
+
 // OIHW conv weight -> split-3 bf16 MFMA A-operand fragments (conv_bf16x6.hip), one K-step = 16 channels x 2 taps:
 // [K-step][3 splits][Cout_pad/16][64 lanes][8]; lane l of cout-tile nt holds W[cout = 16nt + (l&15)][channel = 16cb +
 // 8((l>>4)&1) + j][tap], where (cb, tap) of the lane's half (l>>5) follows the kernel's K-step order:
@@ -160,47 +163,6 @@ std::vector<unsigned short> pack_h2(const float *w, int cout, int cin, int kh, i
         }
     return out;
 }
-
-#ifdef PMP_ABLATION   // measurement library only, with the kernel it feeds
-// Winograd F(2, 3) along x for a 3x3 64 -> 64 convolution (conv_f16x3_wx.hip).  U_p[ky] = sum_kx G[p][kx] w[ky][kx] in fp64, scaled by
-// S = 2^k (max |S U| in [4096, 8192)), two fp16 terms.  Stream [pair P 2][step s 3][position p 4][split 2][cout group 4][64 lanes][8]:
-// a K-step is 16 channels x two vertical taps -  s = 0: (ky0, ky1) of group 2P;  s = 1: ky2 of group 2P and ky2 of group 2P + 1;
-// s = 2: (ky0, ky1) of group 2P + 1.  Lane l of cout group ct: cout 16 ct + (l & 15), channels 8 ((l >> 4) & 1) + j of the tap/group
-// selected by l >> 5.
-std::vector<unsigned short> pack_h2_wx(const float *w, int *scale_exp)
-{
-    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
-    std::vector<float> U((size_t)4 * 3 * 64 * 64);          // [p][ky][co][ci]
-    for (int p = 0; p < 4; ++p)
-        for (int ky = 0; ky < 3; ++ky)
-            for (int co = 0; co < 64; ++co)
-                for (int ci = 0; ci < 64; ++ci) {
-                    double u = 0;
-                    for (int kx = 0; kx < 3; ++kx) u += G[p][kx] * (double)w[(((size_t)co * 64 + ci) * 3 + ky) * 3 + kx];
-                    U[(((size_t)p * 3 + ky) * 64 + co) * 64 + ci] = (float)u;     // |u| <= 1.5 max|w|: a float holds it to 2^-24
-                }
-    const int kexp = h2_scale_exp(U.data(), U.size());
-    if (scale_exp) *scale_exp = kexp;
-    const float S = std::ldexp(1.f, kexp);
-    std::vector<unsigned short> out((size_t)2 * 3 * 4 * 2 * 4 * 64 * 8, 0);
-    for (int P = 0; P < 2; ++P)
-        for (int st = 0; st < 3; ++st) {
-            const int cbA = st == 2 ? 2 * P + 1 : 2 * P, kyA = st == 1 ? 2 : 0;
-            const int cbB = st == 0 ? 2 * P : 2 * P + 1, kyB = st == 1 ? 2 : 1;
-            for (int p = 0; p < 4; ++p)
-                for (int ct = 0; ct < 4; ++ct)
-                    for (int l = 0; l < 64; ++l) {
-                        const int g = l >> 4, cb = (g >> 1) ? cbB : cbA, ky = (g >> 1) ? kyB : kyA;
-                        const int co = ct * 16 + (l & 15), ci0 = cb * 16 + 8 * (g & 1);
-                        float v[8];
-                        for (int j = 0; j < 8; ++j) v[j] = U[(((size_t)p * 3 + ky) * 64 + co) * 64 + ci0 + j] * S;
-                        const size_t base = ((((size_t)(P * 3 + st) * 4 + p) * 2) * 4 + ct) * 64 + l;
-                        split8(v, out.data() + base * 8, out.data() + (base + 4 * 64) * 8);
-                    }
-        }
-    return out;
-}
-#endif
 
 // Stem weights for the MFMA stem (conv_misc.hip: stem_mfma_kernel): ONE k1 x k1 convolution with 32 outputs, top-left
 // anchored (the smaller kernels of the MTT stems are zero-padded into it).  w32: [32][cin][k1][k1].  K is ordered

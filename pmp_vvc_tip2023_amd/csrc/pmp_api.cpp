@@ -137,10 +137,7 @@ static int infer_passes(pmp_ctx *c, bool luma, NetWeights &wq, NetWeights &wb, c
 {
     int rc0;     // weights are packed per datapath, on first use (the load packed the datapath that was current then)
     if ((rc0 = ensure_datapath(c, wq, c->precision)) != PMP_OK || (rc0 = ensure_datapath(c, wb, c->precision)) != PMP_OK) return rc0;
-#ifdef PMP_ABLATION
-    if (c->winograd && c->precision == PMP_PRECISION_F16X3 &&
-        ((rc0 = ensure_datapath(c, wq, 3)) != PMP_OK || (rc0 = ensure_datapath(c, wb, 3)) != PMP_OK)) return rc0;     // Winograd-x streams
-#endif
+    if ((rc0 = abl_prepare_pass(c, wq, wb)) != PMP_OK) return rc0;
     for (int64_t o = 0; o < n; o += c->chunk) {
         const int m = (int)((n - o) < c->chunk ? (n - o) : c->chunk);
         const uint8_t *y = by + o * 68 * 68;
@@ -342,11 +339,8 @@ extern "C" {
 
 const char *pmp_version(void)
 {
-#ifdef PMP_ABLATION
-    return "pmp-hip 0.3-abl (gfx950; f16x3 / bf16x6 split MFMA + fp32 MFMA; MEASUREMENT BUILD with timing-only kernels)";
-#else
-    return "pmp-hip 0.3 (gfx950; f16x3 default, bf16x6 and fp32 MFMA datapaths)";
-#endif
+    if (const char *v = abl_version()) return v;     // a measurement build says so
+    return "pmp-hip 0.4 (gfx950; f16x3 default, bf16x6 and fp32 MFMA datapaths)";
 }
 
 const char *pmp_last_error(const pmp_ctx *ctx) { return ctx ? ctx->err.c_str() : global_err(); }
@@ -363,9 +357,7 @@ int pmp_create(int device_id, pmp_ctx **out)
     if ((e = hipSetDevice(device_id)) != hipSuccess) return hip_fail(nullptr, e, "hipSetDevice");
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return hip_fail(nullptr, e, "hipGetDeviceProperties");
-#ifdef PMP_ABLATION   // measurement library only (libpmp_hip_abl.so): the product library reads no environment variable
-    if (const char *v = getenv("PMP_CONV_VARIANT")) g_conv_variant = atoi(v);
-#endif
+    abl_on_create();     // no-op: the product library reads no environment variable
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
         return set_err(nullptr, PMP_E_NODEVICE, std::string("pmp_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName);
     pmp_ctx *c = new (std::nothrow) pmp_ctx();
@@ -708,16 +700,12 @@ int pmp_cut_blocks(pmp_ctx *c, const void *y, const void *u, const void *v, int 
 
 int pmp_debug_set_conv_variant(int variant)
 {
-#ifdef PMP_ABLATION
-    if (variant < 0 || variant > 4095) return set_err(nullptr, PMP_E_INVALID, "pmp_debug_set_conv_variant: 0..9, or 10 + bits for the timing-only builds");
-    g_conv_variant = variant;
-    return PMP_OK;
-#else
+    int rc;
+    if (abl_set_conv_variant(variant, &rc)) return rc;
     // the product library ships ONE form of every kernel (number 2): there is no process-wide selector in it.  The A/B forms
     // (bit-identical, measured slower or equal) and the timing-only builds live in libpmp_hip_abl.so (make abl)
     if (variant != 2) return set_err(nullptr, PMP_E_INVALID, "pmp_debug_set_conv_variant: this library ships only the default form (2); the A/B and timing-only builds are in libpmp_hip_abl.so (make abl)");
     return PMP_OK;
-#endif
 }
 
 int pmp_debug_set_fusion(pmp_ctx *c, int on)
@@ -732,15 +720,12 @@ int pmp_debug_set_fusion(pmp_ctx *c, int on)
 int pmp_debug_set_winograd(pmp_ctx *c, int on)
 {
     CHECK_CTX(c);
-    const int rc = settle(c);
+    int rc = settle(c);
     if (rc != PMP_OK) return rc;
-#ifdef PMP_ABLATION
-    c->winograd = on ? 1 : 0;
-    return PMP_OK;
-#else       // the Winograd-x kernel did not beat the direct form (profiles/r03_notes.txt): it lives in libpmp_hip_abl.so (make abl)
+    if (abl_set_winograd(c, on, &rc)) return rc;
+    // the Winograd-x kernel did not beat the direct form (profiles/r03_notes.txt): it lives in libpmp_hip_abl.so (make abl)
     if (on) return set_err(c, PMP_E_INVALID, "pmp_debug_set_winograd: the Winograd-x form is built into libpmp_hip_abl.so only (make abl)");
     return PMP_OK;
-#endif
 }
 
 int pmp_debug_conv_bench(pmp_ctx *c, int n, int h, int w, int cin, int cout, int k, int iters, double *ms_f32, double *ms_x6,
@@ -760,36 +745,26 @@ int pmp_debug_conv_bench(pmp_ctx *c, int n, int h, int w, int cin, int cout, int
     const bool h2 = c->precision == PMP_PRECISION_F16X3;   // the split leg follows the context's datapath
     const int kexp = h2_scale_exp(hw.data(), hw.size());
     std::vector<unsigned short> wx = h2 ? pack_h2(hw.data(), cout, cin, k, k, cout, cin, kexp) : pack_x6(hw.data(), cout, cin, k, k, cout, cin);
-    bool wino = false;
-    int kexp_w = 0;
-    std::vector<unsigned short> ww;
-#ifdef PMP_ABLATION
-    wino = h2 && c->winograd && k == 3 && cin == 64 && cout == 64;     // the Winograd-x form of this layer (conv_f16x3_wx.hip)
-    if (wino) ww = pack_h2_wx(hw.data(), &kexp_w);
-#endif
-    unsigned short *dww = nullptr;
+    AblBench ab;
     float *dx = nullptr, *dy = nullptr, *dy2 = nullptr, *dwp = nullptr;
     unsigned short *dxs = nullptr, *dys = nullptr, *dwx = nullptr;
     hipError_t e = hipSuccess;
     auto A = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
     A((void **)&dx, nx * 4); A((void **)&dy, ny * 4); A((void **)&dy2, ny * 4); A((void **)&dwp, wp.size() * 4);
     A((void **)&dxs, nx * 6); A((void **)&dys, ny * 6); A((void **)&dwx, wx.size() * 2);
-    if (wino) A((void **)&dww, ww.size() * 2);
     int rc = PMP_OK;
     if (e != hipSuccess) rc = hip_fail(c, e, "hipMalloc(conv bench)");
     if (rc == PMP_OK) {
         hipMemcpy(dx, hx.data(), nx * 4, hipMemcpyHostToDevice);
         hipMemcpy(dwp, wp.data(), wp.size() * 4, hipMemcpyHostToDevice);
         hipMemcpy(dwx, wx.data(), wx.size() * 2, hipMemcpyHostToDevice);
-        if (wino) hipMemcpy(dww, ww.data(), ww.size() * 2, hipMemcpyHostToDevice);
         ConvMfmaArgs a{};
         a.x = dx; a.w = dwp; a.out = dy; a.N = n; a.H = h; a.W = w; a.Cin = cin; a.Cout = cout; a.KH = a.KW = k; a.relu = 1;
         ConvX6Args b{};
         b.x = dxs; b.x_stride = nx; b.w = dwx; b.out = dys; b.out_stride = ny;
         b.N = n; b.H = h; b.W = w; b.Cin = cin; b.Cout = cout; b.KH = b.KW = k; b.relu = 1;
         b.out_scale = std::ldexp(1.f, -kexp);
-        b.zeros = c->d_sat + 16;
-        if (wino) { b.w_wx = dww; b.wx_out_scale = std::ldexp(1.f, -kexp_w); }
+        abl_bench_prepare(c, ab, hw.data(), k, cin, cout, h2, b);
         auto launch_split = [&]() { return h2 ? launch_conv_h2(c->stream, b) : launch_conv_x6(c->stream, b); };
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
@@ -806,59 +781,7 @@ int pmp_debug_conv_bench(pmp_ctx *c, int n, int h, int w, int cin, int cout, int
         for (int i = 0; i < iters; ++i) launch_split();
         hipEventRecord(e1, c->stream); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
         if (ms_x6) *ms_x6 = ms / iters;
-#ifdef PMP_ABLATION
-        if (!h2 && g_conv_variant == 10 + 128 && k == 3 && cout == 64) {   // in-kernel stamp report (diagnostic build)
-            const int wgs = n * (h / 16) * (w / 16);
-            unsigned long long *ddbg = nullptr;
-            if (hipMalloc((void **)&ddbg, (size_t)wgs * 8 * 8) == hipSuccess) {
-                hipMemset(ddbg, 0, (size_t)wgs * 8 * 8);
-                b.dbg = ddbg;
-                launch_conv_x6(c->stream, b);
-                hipStreamSynchronize(c->stream);
-                std::vector<unsigned long long> hd((size_t)wgs * 8);
-                hipMemcpy(hd.data(), ddbg, hd.size() * 8, hipMemcpyDeviceToHost);
-                double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                unsigned long long tmin = ~0ull, tmax = 0;
-                for (int i = 0; i < wgs; ++i) {
-                    for (int j = 0; j < 8; ++j) if (j != 5) s[j] += (double)hd[(size_t)i * 8 + j];
-                    if (hd[(size_t)i * 8 + 5] < tmin) tmin = hd[(size_t)i * 8 + 5];
-                    if (hd[(size_t)i * 8 + 5] + hd[(size_t)i * 8 + 3] + hd[(size_t)i * 8 + 4] > tmax) tmax = hd[(size_t)i * 8 + 5] + hd[(size_t)i * 8 + 3] + hd[(size_t)i * 8 + 4];
-                }
-                fprintf(stderr, "stamps (mean ticks per workgroup, wave 0): prologue %.0f | K-steps %.0f | wait for staged loads %.0f | "
-                                "LDS store %.0f | barrier %.0f | accumulate total %.0f | epilogue incl. store ack %.0f\n",
-                        s[0] / wgs, s[1] / wgs, s[6] / wgs, s[2] / wgs, s[7] / wgs, s[3] / wgs, s[4] / wgs);
-                b.dbg = nullptr;
-                hipFree(ddbg);
-            }
-        }
-        if (h2 && ((g_conv_variant >= 10 + 128 && g_conv_variant < 10 + 144) || g_conv_variant == 10 + 1152) && k == 3 && cout == 64) {   // 128 + ablation bits 1/2/4; 1152: the three-workgroup form   // in-kernel stamp report (diagnostic build)
-            const int wgs = n * (h / 16) * (w / 16);
-            unsigned long long *ddbg = nullptr;
-            if (hipMalloc((void **)&ddbg, (size_t)wgs * 16 * 8) == hipSuccess) {
-                hipMemset(ddbg, 0, (size_t)wgs * 16 * 8);
-                b.dbg = ddbg;
-                launch_split();
-                hipStreamSynchronize(c->stream);
-                std::vector<unsigned long long> hd((size_t)wgs * 16);
-                hipMemcpy(hd.data(), ddbg, hd.size() * 8, hipMemcpyDeviceToHost);
-                double s[6] = {0, 0, 0, 0, 0, 0};
-                unsigned long long tmin = ~0ull, tmax = 0;
-                for (int i = 0; i < wgs; ++i) {
-                    for (int j = 0; j < 6; ++j) s[j] += (double)hd[(size_t)i * 16 + j];
-                    tmin = std::min(tmin, hd[(size_t)i * 16 + 6]);
-                    tmax = std::max(tmax, hd[(size_t)i * 16 + 7]);
-                }
-                fprintf(stderr, "f16x3 stamps (mean ticks per workgroup, wave 0): prologue %.0f | K-steps %.0f | halo LDS store incl. its wait %.0f | "
-                                "group barrier %.0f | accumulate total %.0f | epilogue incl. store ack %.0f | kernel span %.0f ticks, %d workgroups\n",
-                        s[0] / wgs, s[1] / wgs, s[2] / wgs, s[3] / wgs, s[4] / wgs, s[5] / wgs, (double)(tmax - tmin), wgs);
-                if (const char *dump = getenv("PMP_STAMP_DUMP")) {   // raw stamps, 16 x u64 per workgroup (tools/stamp_overlap.py)
-                    if (FILE *f = fopen(dump, "wb")) { fwrite(hd.data(), 8, hd.size(), f); fclose(f); }
-                }
-                b.dbg = nullptr;
-                hipFree(ddbg);
-            }
-        }
-#endif
+        abl_bench_report(c, ab, h2, n, h, w, k, cout, b, launch_split);
         if (h2) launch_split2_to_f32(c->stream, dys, dy2, ny, ny);
         else launch_split3_to_f32(c->stream, dys, dy2, ny, ny);
         std::vector<float> y1(ny), y2(ny);
@@ -874,7 +797,8 @@ int pmp_debug_conv_bench(pmp_ctx *c, int n, int h, int w, int cin, int cout, int
         hipEventDestroy(e0); hipEventDestroy(e1);
         if (e != hipSuccess) rc = hip_fail(c, e, "conv bench");
     }
-    for (void *p : {(void *)dx, (void *)dy, (void *)dy2, (void *)dwp, (void *)dxs, (void *)dys, (void *)dwx, (void *)dww}) if (p) hipFree(p);
+    abl_bench_free(ab);
+    for (void *p : {(void *)dx, (void *)dy, (void *)dy2, (void *)dwp, (void *)dxs, (void *)dys, (void *)dwx}) if (p) hipFree(p);
     return rc;
 }
 

@@ -31,7 +31,7 @@ struct RBWeights {
     unsigned short *w0x = nullptr, *w2x = nullptr, *wscx = nullptr;  // bf16x6 split packing (conv_bf16x6.hip)
     unsigned short *w0h = nullptr, *w2h = nullptr, *wsch = nullptr;  // f16x3 split packing (conv_f16x3.hip), scaled by
     int k0 = 0, k2 = 0;                                               // 2^k0 (first conv) / 2^k2 (second conv + shortcut)
-    unsigned short *w0w = nullptr, *w2w = nullptr; int k0w = 0, k2w = 0;   // f16x3, 3x3 64->64 blocks: Winograd-x streams (conv_f16x3_wx.hip)
+    AblRB abl;                         // empty in the product library
     bool direct = false;               // 8x8 layers run on the direct kernel
     bool has_sc = false;               // 1x1 shortcut conv (cin != cout); the packed pointers exist per datapath, this flag always
 };
@@ -122,7 +122,7 @@ struct pmp_ctx {
     unsigned *h_sat = nullptr;             // PMP_SAT_SLOTS pinned host words: flag snapshots of the calls still in flight
     uint64_t sat_seq = 0;
     std::deque<pmp::PendingCall> pending;  // calls whose flag has not been looked at yet (+ the post-processing calls after them)
-    int winograd = 0;                      // measurement library: run the 3x3 64->64 convolutions in the Winograd-x form (pmp_debug_set_winograd); always 0 in the product
+    pmp::AblCtx abl;                       // empty in the product library
     int sat_policy = PMP_SAT_RERUN;
     int sat_seen = 0;                      // sticky: some inference call since pmp_clear_saturation saturated
     int64_t sat_reruns = 0;                // calls re-run on the bf16x6 datapath
@@ -163,3 +163,5 @@ struct KScope {
 };
 
 }  // namespace pmp
+
+#include "abl_hooks.h"   // hooks/ in the product build (no-op inlines), abl/ in the measurement library

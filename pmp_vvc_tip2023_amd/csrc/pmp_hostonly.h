@@ -19,10 +19,7 @@ std::vector<float> pack_mfma(const float *w, int cout, int cin, int kh, int kw, 
 std::vector<unsigned short> pack_x6(const float *w, int cout, int cin, int kh, int kw, int cout_pad, int cin_pad);
 std::vector<unsigned short> pack_h2(const float *w, int cout, int cin, int kh, int kw, int cout_pad, int cin_pad, int scale_exp);
 int h2_scale_exp(const float *w, size_t n);
-#ifdef PMP_ABLATION
-// 3x3 64->64 only: Winograd F(2,3)-along-x form of the f16x3 stream (conv_f16x3_wx.hip); *scale_exp receives its power-of-two exponent
-std::vector<unsigned short> pack_h2_wx(const float *w, int *scale_exp);
-#endif
+void h2_split8(const float *v, unsigned short *h0, unsigned short *h1);   // 8 values -> their two fp16 terms (bit patterns), as pack_h2 splits them
 std::vector<unsigned short> pack_stem_h2(const float *w32, int cin, int k1, int scale_exp);
 std::vector<float> pack_plain(const float *w, int cout, int cin, int kh, int kw);
 

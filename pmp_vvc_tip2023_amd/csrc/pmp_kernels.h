@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "abl_types.h"   // hooks/ in the product build (empty structs), abl/ in the measurement library
+
 namespace pmp {
 
 // ------------------------------------------------------------------------------------------------ conv (MFMA)
@@ -25,9 +27,6 @@ struct ConvMfmaArgs {
     int relu, pool;
 };
 hipError_t launch_conv_mfma(hipStream_t s, const ConvMfmaArgs &a);
-#ifdef PMP_ABLATION
-extern int g_conv_variant;  // measurement library only (make abl): see pmp_debug_set_conv_variant
-#endif
 
 // ------------------------------------------------------------------------------------------------ conv (bf16 x 6)
 // Same operation on "split-3" activations (three bf16 planes per tensor, conv_bf16x6.hip).  *_stride = elements between
@@ -43,11 +42,9 @@ struct ConvX6Args {
     float *out_f32;
     int N, H, W, Cin, Csc, Cout, KH, KW;
     int relu, pool;
-    unsigned long long *dbg;   // diagnostic builds only: 8 stamps per workgroup (nullptr otherwise)
     float out_scale;           // f16x3 only: 1/S of the power-of-two weight scaling (conv_f16x3.hip)
     unsigned *sat;             // f16x3 only: sticky flag raised when a stored activation exceeded the fp16 range (may be nullptr)
-    const void *zeros;         // f16x3 only: >= 16 zero bytes in device memory (source of out-of-image halo pieces, conv_f16x3_t32.hip)
-    const unsigned short *w_wx; float wx_out_scale;   // f16x3, 3x3 64->64 only: Winograd-x weight stream (pack_h2_wx) and its 1/S (conv_f16x3_wx.hip)
+    AblConvArgs abl;           // empty in the product library
 };
 hipError_t launch_conv_x6(hipStream_t s, const ConvX6Args &a);
 hipError_t launch_f32_to_split3(hipStream_t s, const float *x, unsigned short *out, size_t n, size_t plane_stride);
@@ -55,16 +52,6 @@ hipError_t launch_split3_to_f32(hipStream_t s, const unsigned short *x, float *o
 // Same operation on "split-2" activations (two fp16 planes) with three fp16 MFMA products per term (conv_f16x3.hip).
 // Weights packed [K-step][2 splits][Cout/16][64 lanes][8 fp16], pre-multiplied by 1/out_scale.
 hipError_t launch_conv_h2(hipStream_t s, const ConvX6Args &a);
-#ifdef PMP_ABLATION
-// conv_f16x3_t32.hip (measurement library only): the 3x3 64->64 trunk convolution on 32x16 tiles (LDS-DMA halo, hand-counted vmcnt)
-bool conv_h2_t32_applicable(const ConvX6Args &a);
-hipError_t launch_conv_h2_t32(hipStream_t s, const ConvX6Args &a);
-#endif
-#ifdef PMP_ABLATION
-// conv_f16x3_wx.hip (measurement library only): the 3x3 64->64 convolution with a 1-D Winograd F(2,3) transform along x (1.5x fewer MFMAs)
-bool conv_h2_wx_applicable(const ConvX6Args &a);
-hipError_t launch_conv_h2_wx(hipStream_t s, const ConvX6Args &a);
-#endif
 hipError_t launch_f32_to_split2(hipStream_t s, const float *x, unsigned short *out, size_t n, size_t plane_stride, unsigned *sat = nullptr);
 hipError_t launch_split2_to_f32(hipStream_t s, const unsigned short *x, float *out, size_t n, size_t plane_stride);
 

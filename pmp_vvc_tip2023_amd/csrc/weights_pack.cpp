@@ -118,12 +118,7 @@ int load_rb(pmp_ctx *c, const Blob &b, Uploader &up, const std::string &name, in
             if ((rc = up.upload16(pack_h2(w2, cout, cout, k, k, r.cout_pad, r.cout_pad, r.k2), &r.w2h))) return rc;
             if (wsc && (rc = up.upload16(pack_h2(wsc, cout, cin, 1, 1, r.cout_pad, r.cin_pad, r.k2), &r.wsch))) return rc;
         }
-#ifdef PMP_ABLATION
-        if ((mask & (1u << 3)) && k == 3 && cin == 64 && cout == 64 && !r.w0w) {     // pseudo-datapath 3: the Winograd-x form of the trunk blocks (measurement library)
-            if ((rc = up.upload16(pack_h2_wx(w0, &r.k0w), &r.w0w))) return rc;
-            if ((rc = up.upload16(pack_h2_wx(w2, &r.k2w), &r.w2w))) return rc;
-        }
-#endif
+        if ((rc = abl_pack_rb(w0, w2, k, cin, cout, mask, r, [&](const std::vector<unsigned short> &v, unsigned short **dst) { return up.upload16(v, dst); }))) return rc;
     }
     return PMP_OK;
 }
@@ -267,7 +262,7 @@ int load_net_weights(pmp_ctx *c, int net_id, int qp, const float *blob, const pm
     }
     for (int i = 0; i < ndesc; ++i) nw.descs[i].name = nw.names[i].c_str();
     Blob b{nw.host.data(), nw.descs.data(), ndesc};
-    const int rc = build_net(c, net_id, b, nw, (1u << c->precision) | (c->winograd ? 1u << 3 : 0u));
+    const int rc = build_net(c, net_id, b, nw, (1u << c->precision) | abl_pack_mask(c));
     if (rc != PMP_OK) { free_net_weights(nw); return rc; }
     nw.loaded = true;
     const int key = net_id * 100 + qp;

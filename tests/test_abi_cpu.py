@@ -178,6 +178,17 @@ def test_product_library_has_no_ablation_knobs(lib):
     for sym in (b"conv_h2_t32", b"conv_h2_persist_kernel", b"conv_h2_ld_kernel", b"conv_h2_wx_kernel", b"pack_h2_wx"):
         assert sym not in blob, sym                        # ... nor the Winograd-x experiment of round 3, nor its weight packer
     assert b"abl" not in lib.pmp_version()
+    # ... and the SOURCES of the product library carry no measurement code either: no conditional compilation on the measurement build, no
+    # timing-only template parameter, no stamp helper - the notebook lives under csrc/abl/ (and tools/experiments/), behind the no-op
+    # hooks of csrc/hooks/ (same header names as csrc/abl/'s, chosen by include path: make vs make abl)
+    import re
+    csrc = os.path.join(os.path.dirname(_lib.LIB_PATH), "csrc")
+    product = [f for f in os.listdir(csrc) if f.endswith((".hip", ".cpp", ".h"))] + ["hooks/abl_types.h", "hooks/abl_hooks.h"]
+    assert len(product) >= 20 and os.path.isdir(os.path.join(csrc, "abl"))
+    for f in product:
+        src = open(os.path.join(csrc, f)).read()
+        assert "PMP_ABLATION" not in src and "g_conv_variant" not in src and "s_memtime" not in src, f
+        assert not re.search(r"\bABL\b", src), f
     assert os.path.getsize(_lib.LIB_PATH) < 2.3e6          # 2.78 MB with the notebook inside (round 2); 2.0 MB + the fused 16x16 tails (chain16.hip, round 4)
 
 

@@ -4,7 +4,9 @@ kernel forms on shapes the nets never launch against the exact fp32 kernel.  Run
 
     python tools/variants_agree.py
 
-A regression check of the notebook, not a parity test: the product library ships none of these forms."""
+A regression check of the notebook, not a parity test: the product library ships none of these forms.  Since round 4
+the notebook forms of the three convolution kernel files are separate sources (csrc/abl/), so the first check is that the measurement
+library's DEFAULT form still computes what the product library computes, bit for bit, on every datapath."""
 import ctypes as C
 import os
 import sys
@@ -14,13 +16,32 @@ import numpy as np
 
 from pmp_vvc_tip2023_amd import _lib, engine
 
-_lib.load(_lib.ABL_LIB_PATH)
 g1 = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "g1_qt.npz"))
-eng = engine.Engine(0, allow_synthetic_mtt=True)
-eng.set_precision("f16x3")
 y = np.concatenate([g1["block_y"]] * 8)              # 128 blocks: several tiles per persistent workgroup at 64x64
-ref = eng.inference_pre_QBD("Luma", 22, y)
+u = np.concatenate([g1["block_u"]] * 8)
+v = np.concatenate([g1["block_v"]] * 8)
 bad = 0
+product = {}
+_lib.load(_lib.LIB_PATH)
+eng = engine.Engine(0, allow_synthetic_mtt=True)
+for prec in ("f16x3", "bf16x6", "fp32"):
+    eng.set_precision(prec)
+    for comp in ("Luma", "Chroma"):
+        product[(prec, comp)] = eng.inference_pre_QBD(comp, 22, y, u, v)
+eng.close()
+_lib._lib = None                                     # both builds in one process (ctypes loads them RTLD_LOCAL): forget the first handle
+_lib.load(_lib.ABL_LIB_PATH)
+eng = engine.Engine(0, allow_synthetic_mtt=True)
+assert b"abl" in eng.lib.pmp_version()
+for prec in ("f16x3", "bf16x6", "fp32"):
+    eng.set_precision(prec)
+    for comp in ("Luma", "Chroma"):
+        got = eng.inference_pre_QBD(comp, 22, y, u, v)
+        same = all(np.array_equal(a, b) for a, b in zip(product[(prec, comp)], got))
+        bad += not same
+        print("product library vs measurement library, default forms, %s %s: logits %s" % (prec, comp, "bit-identical" if same else "DIFFER"), flush=True)
+eng.set_precision("f16x3")
+ref = eng.inference_pre_QBD("Luma", 22, y)
 for variant in (1, 3, 4, 5, 6, 7, 8, 9):
     assert eng.lib.pmp_debug_set_conv_variant(variant) == 0
     got = eng.inference_pre_QBD("Luma", 22, y)
