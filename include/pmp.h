@@ -86,7 +86,7 @@ int pmp_synchronize(pmp_ctx *ctx);
 int pmp_set_chunk(pmp_ctx *ctx, int blocks);
 int64_t pmp_get_workspace_bytes(const pmp_ctx *ctx);
 
-/* Convolution datapath.  All three are fp32-accurate; results differ in the last bits only.
+/* Convolution datapath.  All three are fp32-accurate (EXPERIMENTS.md, precision study); results differ in the last bits only.
  *   PMP_PRECISION_F32    v_mfma_f32_16x16x4_f32, exact fp32 fmaf chain
  *   PMP_PRECISION_BF16X6 every fp32 operand carried as 3 bf16 terms, 6 bf16 MFMA products, fp32 accumulate
  *   PMP_PRECISION_F16X3  (default) every fp32 operand carried as 2 fp16 terms (weights pre-scaled by a power of two),
@@ -227,12 +227,12 @@ int pmp_ktime_get(pmp_ctx *ctx, int cls, int64_t *launches, double *ms, double *
  *      here (PMP_E_INVALID): it has no process-wide kernel selector.  The forms that were built, parity-tested and measured slower
  *      than or equal to the shipped ones (1, 3..9; bit-identical results) and the timing-only builds (10 and above; WRONG results)
  *      exist only in the measurement library libpmp_hip_abl.so (`make abl`), where this call selects them process-wide for
- *      in-process A/B timing (tools/conv_ab.py, tools/variants_agree.py; the list is in conv_f16x3.hip, the numbers in DESIGN.md 4.1a). ---- */
+ *      in-process A/B timing (tools/conv_ab.py, tools/variants_agree.py; the list is in csrc/abl/conv_f16x3.hip, the numbers in EXPERIMENTS.md). ---- */
 int pmp_debug_set_conv_variant(int variant);
 
 /* ---- measurement hook (f16x3 datapath): run the 3x3 64->64 convolutions - 55 % of the luma step - in the Winograd F(2,3)-along-x
  *      form (conv_f16x3_wx.hip: 1.5x fewer MFMAs, fp32-equivalent logits within the 1e-3 tolerance, not bit-identical to the direct
- *      form).  It did not beat the direct kernels (profiles/r03_notes.txt), so like the other forms that lost their
+ *      form).  It did not beat the direct kernels (EXPERIMENTS.md, profiles/r03_notes.txt), so like the other forms that lost their
  *      A/B it exists in the measurement library libpmp_hip_abl.so only (`make abl`; tools/wx_probe.py, tools/wx_ablate.py): the
  *      product library accepts on = 0 and answers PMP_E_INVALID to anything else. ---- */
 int pmp_debug_set_winograd(pmp_ctx *ctx, int on);

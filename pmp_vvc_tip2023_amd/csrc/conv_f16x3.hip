@@ -21,7 +21,7 @@
 //   top: request the NEXT K-step's w0 into a second register set, read this K-step's x1 fragments, issue a slice of the halo
 //   phase A: x0*w1 -> request the next w1 into the same registers     phase B1: x0*w0 -> read the next K-step's x0
 //   phase B2: x1*w0 -> move the prefetched w0 over
-// Measurements: DESIGN.md 4.1a.  The forms of this kernel that were built, parity-tested and measured no better (persistent, loader-wave,
+// Measurements: DESIGN.md 4.1, EXPERIMENTS.md.  The forms of this kernel that were built, parity-tested and measured no better (persistent, loader-wave,
 // 512-thread, 32x16-tile, Winograd-x, two-workgroup forms) and its timing-only builds live in abl/ (measurement library, `make abl`).
 #include <cstdio>
 #include <type_traits>

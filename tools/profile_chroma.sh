@@ -1,5 +1,5 @@
 set -u
-OUT=$PWD/gpurun_out/prof_r03c_chroma
+OUT=$PWD/gpurun_out/prof_${1:-r04}_chroma
 mkdir -p $OUT
 export TMPDIR=/tmp
 BENCH="python3 $PWD/bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-extras --comp Chroma"

@@ -8,6 +8,7 @@ os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
     name = re.sub(r"\(.*$", "", name)
     m = re.search(r"(conv_mfma_kernel)<(\d+), ?(\d+), ?(\d+)>", name)
     if m:
@@ -15,11 +16,12 @@ def short(name):
     m = re.search(r"(conv_x6_kernel)<(\d+), ?(\d+), ?(\d+)", name)
     if m:
         return "conv_x6_kernel<%s, %s, %s>" % m.groups()[1:]
-    m = re.search(r"(conv_h2_kernel)<(\d+), ?(\d+), ?(\d+), ?(\w+)(?:, ?(\d+), ?(\w+))?", name)
-    if m:   # the trailing flag of the template list: the 168-VGPR three-workgroups-per-CU form
-        return "conv_h2_kernel<%s, %s, %s, sc=%s>%s" % (m.group(2), m.group(3), m.group(4), m.group(5), " 3wg" if m.group(7) in ("true", "1") else "")
+    m = re.search(r"(conv_h2_kernel)<(\d+), ?(\d+), ?(\d+), ?(\w+)(?:, ?(\d+), ?(\w+))?(?:, ?(\w+))?", name)
+    if m:   # product: <KH, KW, NT, SC[, LEAN]>; notebook (csrc/abl): <KH, KW, NT, SC, ABL, LEAN, W8>.  LEAN = the 168-VGPR three-workgroups-per-CU form
+        lean = m.group(7) if m.group(6) is not None else m.group(8)
+        return "conv_h2_kernel<%s, %s, %s, sc=%s>%s" % (m.group(2), m.group(3), m.group(4), m.group(5), " 3wg" if lean in ("true", "1") else "")
     name = name.replace("void ", "").replace("pmp::", "").replace("(anonymous namespace)::", "")
-    return name[:70]
+    return name[:70] or "?"
 
 
 lines = []
