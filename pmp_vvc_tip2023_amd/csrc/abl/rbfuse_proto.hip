@@ -160,6 +160,8 @@ __global__ __launch_bounds__(512, 2) void rb64_fused_kernel(RbFuseArgs a)
         RBF_GROUP(0) RBF_GROUP(1) RBF_GROUP(2) RBF_GROUP(3)
 #undef RBF_GROUP
     }
+    C16Pass<9, 4, 4> pw2;              // phase 2's first weight fragments travel while the intermediate is written
+    if (!(ABL & 4)) c16_wstart(pw2, a.w2);
     // intermediate: 1/S, ReLU, zero outside the image, split -> mid[group][18x18 px][16 ch]
     if (!(ABL & 16)) {
 #pragma unroll
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(512, 2) void rb64_fused_kernel(RbFuseArgs a)
     // ---- phase 2
     f32x4 acc[8];
     c16_zero<4>(acc);
-    if (!(ABL & 4)) c16_accumulate<9, 4, 4>(mid, a.w2, acc);
+    if (!(ABL & 4)) c16_accumulate<9, 4, 4>(mid, a.w2, acc, pw2);
     const int ct = C16Tile<4>::ct(), row0 = C16Tile<4>::row0();
     if (ABL & 8) {
         float s = 0.f;

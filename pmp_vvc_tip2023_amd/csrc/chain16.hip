@@ -43,6 +43,8 @@ __global__ __launch_bounds__(512, 2) void msbd_branch16_kernel(MsbdBranch16Args 
     const unsigned short *x5 = a.x5 + (size_t)n * 4 * 4096;
     char *S0 = slots, *S2 = slots + 2 * C16_SLOT, *S4 = slots + 4 * C16_SLOT;
     float amax = 0.f;
+    C16Pass<9, 2, 4> pb0;            // first pass of a branch trunk: started in front of whatever precedes it
+    c16_wstart(pb0, a.b1[0].w0);
     c16_clear_slots(slots);
     __syncthreads();
     c16_load_image(S0, x5, a.x5_stride, 4);
@@ -50,9 +52,11 @@ __global__ __launch_bounds__(512, 2) void msbd_branch16_kernel(MsbdBranch16Args 
 
     auto branch = [&](const C16RB r0, const C16RB r1, const C16RB r2, const float *hw, const float *hb, int layer) __attribute__((always_inline)) {
         // trunk_B: 64 ch in S0..3 -> 32 ch (S0..1) -> 16 ch (S2) -> 8 ch fp32 (f0) -> head
-        amax = c16_rb<2, 4, true, false, C16_IMG>(r0, S0, S4, C16Epi{0.f, nullptr, nullptr, 0, S0, nullptr}, amax);
-        amax = c16_rb<1, 2, true, false, C16_IMG>(r1, S0, S4, C16Epi{0.f, nullptr, nullptr, 0, S2, nullptr}, amax);
-        amax = c16_rb<1, 1, true, false, C16_F32>(r2, S2, S4, C16Epi{0.f, nullptr, nullptr, 0, nullptr, f0}, amax);
+        C16Pass<9, 1, 2> pb1;
+        C16Pass<9, 1, 1> pb2;
+        amax = c16_rb<2, 4, true, false, C16_IMG>(r0, S0, S4, C16Epi{0.f, nullptr, nullptr, 0, S0, nullptr}, amax, pb0, [&]() __attribute__((always_inline)) { c16_wstart(pb1, r1.w0); });
+        amax = c16_rb<1, 2, true, false, C16_IMG>(r1, S0, S4, C16Epi{0.f, nullptr, nullptr, 0, S2, nullptr}, amax, pb1, [&]() __attribute__((always_inline)) { c16_wstart(pb2, r2.w0); });
+        amax = c16_rb<1, 1, true, false, C16_F32>(r2, S2, S4, C16Epi{0.f, nullptr, nullptr, 0, nullptr, f0}, amax, pb2, []() {});
         if (tid < 256) {
             float acc0, acc1;
             c16_head<16>(f0, hw, hb, 2, tid, acc0, acc1);
@@ -79,8 +83,11 @@ __global__ __launch_bounds__(512, 2) void msbd_branch16_kernel(MsbdBranch16Args 
     }
     __syncthreads();
     // trunk_Att1: 3 -> 32 (S4..5), 32 -> 64 gated by x5 (S0..3)
-    amax = c16_rb<2, 1, true, false, C16_IMG>(a.att[0], S0, S4, C16Epi{0.f, nullptr, nullptr, 0, S4, nullptr}, amax);
-    amax = c16_rb<4, 2, true, true, C16_IMG>(a.att[1], S4, S0, C16Epi{0.f, nullptr, x5, a.x5_stride, S0, nullptr}, amax);
+    C16Pass<9, 2, 1> pa0;
+    C16Pass<9, 4, 2> pa1;
+    c16_wstart(pa0, a.att[0].w0);
+    amax = c16_rb<2, 1, true, false, C16_IMG>(a.att[0], S0, S4, C16Epi{0.f, nullptr, nullptr, 0, S4, nullptr}, amax, pa0, [&]() __attribute__((always_inline)) { c16_wstart(pa1, a.att[1].w0); });
+    amax = c16_rb<4, 2, true, true, C16_IMG>(a.att[1], S4, S0, C16Epi{0.f, nullptr, x5, a.x5_stride, S0, nullptr}, amax, pa1, [&]() __attribute__((always_inline)) { c16_wstart(pb0, a.b2[0].w0); });
     branch(a.b2[0], a.b2[1], a.b2[2], a.head_w[1], a.head_b[1], 1);
     sat_report(a.sat, amax);
 }
@@ -104,12 +111,14 @@ __global__ __launch_bounds__(512, 2) void qt_tail16_kernel(QtTail16Args a)
     float *x5 = F;                                  // [2][256][16]
     float *p2 = F + 8192, *p4 = p2 + 2 * 1024, *p8 = p4 + 2 * 256;     // [2][64][16], [2][16][16], [2][4][16]
     float amax = 0.f;
+    C16Pass<9, 2, 4> pq3;
+    c16_wstart(pq3, a.q3.w0);
     c16_clear_slots(lds);
     __syncthreads();
     c16_load_image(S0, a.x4 + (size_t)n * 4 * 4096, a.x4_stride, 4);
     __syncthreads();
     // resblock_q3: 64 -> 32, output fp32 (the multi-scale pool reads it).  Its intermediate uses S4..5, which then becomes the fp32 area.
-    amax = c16_rb<2, 4, true, false, C16_F32>(a.q3, S0, S4, C16Epi{0.f, nullptr, nullptr, 0, nullptr, x5}, amax);
+    amax = c16_rb<2, 4, true, false, C16_F32>(a.q3, S0, S4, C16Epi{0.f, nullptr, nullptr, 0, nullptr, x5}, amax, pq3, []() {});
     // multi-scale pool (conv_misc.hip: multipool_concat_kernel), both groups
     for (int i = tid; i < 2 * 1024; i += 512) {
         const int cb = i >> 10, j = i & 1023, c = j & 15, x = (j >> 4) & 7, y = j >> 7;
@@ -145,26 +154,34 @@ __global__ __launch_bounds__(512, 2) void qt_tail16_kernel(QtTail16Args a)
     // resblock_q4: 128 -> 32.  First conv: 8 groups = 4 pairs of 9 K-steps; second conv: 32 -> 32 from S2..3, then the 1x1 shortcut over x6
     c16_zero<2>(acc);
     for (int p = 0; p < 4; ++p) {
+        C16Pass<9, 2, 2> pp;
+        c16_wstart(pp, a.q4.w0 + (size_t)p * 9 * (2 * 2 * 64 * 8));
         x6_pair(p);
         __syncthreads();
-        c16_accumulate<9, 2, 2>(S0, a.q4.w0 + (size_t)p * 9 * (2 * 2 * 64 * 8), acc);
+        c16_accumulate<9, 2, 2>(S0, a.q4.w0 + (size_t)p * 9 * (2 * 2 * 64 * 8), acc, pp);
         __syncthreads();
     }
+    C16Pass<9, 2, 2> pq4;
+    c16_wstart(pq4, a.q4.w2);
     amax = c16_epilogue<2, false, false, C16_IMG>(acc, C16Epi{a.q4.s0, nullptr, nullptr, 0, S2, nullptr}, amax);
     __syncthreads();
     c16_zero<2>(acc);
-    c16_accumulate<9, 2, 2>(S2, a.q4.w2, acc);
+    c16_accumulate<9, 2, 2>(S2, a.q4.w2, acc, pq4);
     for (int p = 0; p < 4; ++p) {
+        C16Pass<1, 2, 2> pp;
+        c16_wstart(pp, a.q4.wsc + (size_t)p * (2 * 2 * 64 * 8));
         x6_pair(p);
         __syncthreads();
-        c16_accumulate<1, 2, 2>(S0, a.q4.wsc + (size_t)p * (2 * 2 * 64 * 8), acc);
+        c16_accumulate<1, 2, 2>(S0, a.q4.wsc + (size_t)p * (2 * 2 * 64 * 8), acc, pp);
         __syncthreads();
     }
+    C16Pass<9, 2, 2> pq5;
+    c16_wstart(pq5, a.q5.w0);
     amax = c16_epilogue<2, false, false, C16_IMG>(acc, C16Epi{a.q4.s2, nullptr, nullptr, 0, S0, nullptr}, amax);   // x7 -> S0..1 (every wave is past the last barrier)
     __syncthreads();
     // resblock_q5: 32 -> 32, identity shortcut, max_pool2d(2) -> fp32 [2][64][16] over the dead x5
     float *x8 = F;
-    amax = c16_rb<2, 2, false, false, C16_POOL>(a.q5, S0, S2, C16Epi{0.f, nullptr, nullptr, 0, nullptr, x8}, amax);
+    amax = c16_rb<2, 2, false, false, C16_POOL>(a.q5, S0, S2, C16Epi{0.f, nullptr, nullptr, 0, nullptr, x8}, amax, pq5, []() {});
     // resblock_q6 on the 8x8 map (conv_misc.hip: conv_direct8_kernel - fp32 FMA chains: taps row-major, channels ascending, shortcut last);
     // one (pixel, cout) chain per thread
     float *t8 = F + 2048, *y8 = t8 + 1024;          // [64][16] each, channels 8..15 zero

@@ -52,29 +52,51 @@ struct C16Tile {
     __device__ __forceinline__ static int row0() { return ((int)(threadIdx.x >> 6) / NT) * RW; }
 };
 
-// One convolution pass (T = 9: 3x3, T = 1: 1x1 on the same halo images) over the CB source groups at `src` into the wave's accumulators.
-// Fully unrolled.  A K-step runs in sub-steps of four rows; the weight fragments (L2 / L1 hits) are requested D K-steps ahead into a
-// register ring, the pixel fragments of the next sub-step are read from LDS during this one's MFMAs.  Per accumulator the order is the
-// launch path's: x0*w1, x0*w0, x1*w0, K-step after K-step.
+// The weight ring of one convolution pass: the fragments of the next D K-steps.  c16_wstart requests the first D - the caller does that
+// as early as the registers allow, in front of the epilogue and the barrier that precede the pass (weights do not depend on activations):
+// a pass that starts with its own requests waits a full L2 round trip before its first MFMA, 24 times per block.
 template <int T, int NT, int CB>
-__device__ __forceinline__ void c16_accumulate(const char *src, const unsigned short *wpk, f32x4 (&acc)[C16Tile<NT>::RW])
+struct C16Pass {
+    static constexpr bool paired = !(CB & 1) && (T & 1);
+    static constexpr int NS = paired ? (CB / 2) * T : CB * ((T + 1) / 2);
+    static constexpr int D = NS < 6 ? NS : 6;           // K-steps of lead (8 registers each)
+    f16x8 wq[D][2];
+};
+
+template <int T, int NT, int CB>
+__device__ __forceinline__ void c16_wload(C16Pass<T, NT, CB> &p, const unsigned short *wpk, int st)
+{
+    // (explicitly global: a pointer that reached this point through a struct is generic to hipcc, and a flat load counts on both wait counters)
+    const C16_GLOBAL f16x8 *wl = (const C16_GLOBAL f16x8 *)wpk + (threadIdx.x & 63) + C16Tile<NT>::ct() * 64;
+    p.wq[st % C16Pass<T, NT, CB>::D][0] = wl[(size_t)st * (2 * NT * 64)];
+    p.wq[st % C16Pass<T, NT, CB>::D][1] = wl[(size_t)st * (2 * NT * 64) + NT * 64];
+}
+
+template <int T, int NT, int CB>
+__device__ __forceinline__ void c16_wstart(C16Pass<T, NT, CB> &p, const unsigned short *wpk)
+{
+    if (!C16Tile<NT>::active()) return;
+#pragma unroll
+    for (int st = 0; st < C16Pass<T, NT, CB>::D; ++st) c16_wload(p, wpk, st);
+}
+
+// One convolution pass (T = 9: 3x3, T = 1: 1x1 on the same halo images) over the CB source groups at `src` into the wave's accumulators;
+// its first weight fragments are on their way (c16_wstart).  Fully unrolled.  A K-step runs in sub-steps of four rows; the weight
+// fragments (L2 / L1 hits) are requested D K-steps ahead into the ring, the pixel fragments of the next sub-step are read from LDS during
+// this one's MFMAs.  Per accumulator the order is the launch path's: x0*w1, x0*w0, x1*w0, K-step after K-step.
+template <int T, int NT, int CB>
+__device__ __forceinline__ void c16_accumulate(const char *src, const unsigned short *wpk, f32x4 (&acc)[C16Tile<NT>::RW], C16Pass<T, NT, CB> &p)
 {
     typedef C16Tile<NT> WT;
-    constexpr bool paired = !(CB & 1) && (T & 1);
-    constexpr int NS = paired ? (CB / 2) * T : CB * ((T + 1) / 2);
-    constexpr int D = NS < 6 ? NS : 6;                  // K-steps of lead (8 registers each)
+    constexpr int NS = C16Pass<T, NT, CB>::NS, D = C16Pass<T, NT, CB>::D;
     constexpr int SUB = WT::RW / 4, NTK = NS * SUB;
     if (!WT::active()) return;
     const int lane = threadIdx.x & 63, xl = lane & 15, g = lane >> 4;
     const char *pbase = src + (WT::row0() * 18 + xl) * 32 + (g & 1) * 16;
     const bool hi = (g >> 1) != 0;
-    // (explicitly global: a pointer that reached this point through a struct is generic to hipcc, and a flat load counts on both wait counters)
-    const C16_GLOBAL f16x8 *wl = (const C16_GLOBAL f16x8 *)wpk + lane + WT::ct() * 64;
-    f16x8 wq[D][2], xq[2][2][4];
-    auto wload = [&](int st) __attribute__((always_inline)) {
-        wq[st % D][0] = wl[(size_t)st * (2 * NT * 64)];
-        wq[st % D][1] = wl[(size_t)st * (2 * NT * 64) + NT * 64];
-    };
+    f16x8 (&wq)[D][2] = p.wq;
+    f16x8 xq[2][2][4];
+    auto wload = [&](int st) __attribute__((always_inline)) { c16_wload(p, wpk, st); };
     auto xload = [&](int tk) __attribute__((always_inline)) {
         const int st = tk / SUB, h = tk % SUB;
         const char *p = pbase + (hi ? c16_step_off<T, CB>(st, 1) : c16_step_off<T, CB>(st, 0)) + h * 4 * C16_ROW;
@@ -84,8 +106,6 @@ __device__ __forceinline__ void c16_accumulate(const char *src, const unsigned s
             xq[tk & 1][1][m] = *reinterpret_cast<const f16x8 *>(p + C16_PLN + m * C16_ROW);
         }
     };
-#pragma unroll
-    for (int st = 0; st < D; ++st) wload(st);
     xload(0);
 #pragma unroll
     for (int tk = 0; tk < NTK; ++tk) {
@@ -189,18 +209,24 @@ struct C16RB {                    // a ResidualBlock's f16x3 streams (RBWeights)
 
 // ResidualBlock on LDS images: t = relu(conv3x3(in)) -> `mid`; out = relu(conv3x3(t) + (shortcut1x1(in) | in)) [* gate] -> `out` in the
 // form OUT.  NT = output channel groups, CB_IN = input groups, SC: 1x1 shortcut convolution (cin != cout) or identity residual.
-// `out` may alias `in` or `mid` (registers -> barrier -> LDS).
-template <int NT, int CB_IN, bool SC, bool GATE, int OUT>
-__device__ __forceinline__ float c16_rb(const C16RB w, const char *in, char *mid, C16Epi e, float amax)
+// `out` may alias `in` or `mid` (registers -> barrier -> LDS).  `p1` = the first pass's weight ring, started by the caller;
+// `start_next()` starts whatever pass follows this block (it runs in front of the block's last epilogue).
+template <int NT, int CB_IN, bool SC, bool GATE, int OUT, class Next>
+__device__ __forceinline__ float c16_rb(const C16RB w, const char *in, char *mid, C16Epi e, float amax, C16Pass<9, NT, CB_IN> &p1, Next start_next)
 {
     f32x4 acc[C16Tile<NT>::RW];
     c16_zero<NT>(acc);
-    c16_accumulate<9, NT, CB_IN>(in, w.w0, acc);
+    c16_accumulate<9, NT, CB_IN>(in, w.w0, acc, p1);
+    C16Pass<9, NT, NT> p2;
+    C16Pass<1, NT, CB_IN> p3;
+    c16_wstart(p2, w.w2);
+    if (SC) c16_wstart(p3, w.wsc);
     amax = c16_epilogue<NT, false, false, C16_IMG>(acc, C16Epi{w.s0, nullptr, nullptr, 0, mid, nullptr}, amax);   // `mid` is nobody's source: no barrier before
     __syncthreads();
     c16_zero<NT>(acc);
-    c16_accumulate<9, NT, NT>(mid, w.w2, acc);
-    if (SC) c16_accumulate<1, NT, CB_IN>(in, w.wsc, acc);      // ResidualBlock, Model_QBD.py:33-38
+    c16_accumulate<9, NT, NT>(mid, w.w2, acc, p2);
+    if (SC) c16_accumulate<1, NT, CB_IN>(in, w.wsc, acc, p3);      // ResidualBlock, Model_QBD.py:33-38
+    start_next();
     e.res = in;
     e.inv_scale = w.s2;
     __syncthreads();                  // every wave is done reading `in` and `mid`: the output may land on either
