@@ -131,7 +131,8 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
 
 // ---- MFMA stem (f16x3 datapath).  The same first layers as stem_kernel, as ONE top-left anchored K1 x K1 convolution with 32
 // outputs on the fp16 matrix cores: pixels (0..255) are exact in fp16, so they need one term; the plane built from the QT
-// logits gets the usual two (x0, x1); weights are two scaled fp16 terms (pack_stem_h2).  Products: x0*w0 + x0*w1 (+ x1*w0
+// logits gets the usual two (x0, x1); weights are THREE scaled fp16 terms (pack_stem_h2: the fp32 weight exactly, so every pixel product
+// is exact - this layer's weight error is the one the Luma_Q net amplifies most).  Products: x0*w2 + x0*w1 + x0*w0 (+ x1*w0
 // for the logit plane).  There is no channel dimension to make a lane's 8 K-values contiguous - they are 8 consecutive
 // pixels of an input row starting at an arbitrary column - so the B fragments are gathered with 2-byte LDS reads; one
 // gathered fragment feeds 4-6 MFMAs (two cout groups x the products).  Workgroup = one block; a wave walks batches of 8
@@ -214,15 +215,17 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(StemArgs a)
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const f16x8 *wk = wl + (size_t)ks * (2 * 2 * 64);
-            const f16x8 w00 = wk[0], w01 = wk[64], w10 = wk[128], w11 = wk[192];   // [split][nt]
+            const f16x8 *wk = wl + (size_t)ks * (3 * 2 * 64);
+            const f16x8 w00 = wk[0], w01 = wk[64], w10 = wk[128], w11 = wk[192], w20 = wk[256], w21 = wk[320];   // [split][nt]
 #pragma unroll
             for (int m = 0; m < RB; ++m) {
                 const f16x8 bx = win[(m + ks * STEP) & 7];
-                acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w00, bx, acc[m][0], 0, 0, 0);
-                acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01, bx, acc[m][1], 0, 0, 0);
+                acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w20, bx, acc[m][0], 0, 0, 0);     // smallest terms first
+                acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w21, bx, acc[m][1], 0, 0, 0);
                 acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w10, bx, acc[m][0], 0, 0, 0);
                 acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w11, bx, acc[m][1], 0, 0, 0);
+                acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w00, bx, acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01, bx, acc[m][1], 0, 0, 0);
                 if (MSBD) {
                     const f16x8 b1 = win1[(m + ks * STEP) & 7];
                     acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w00, b1, acc[m][0], 0, 0, 0);

@@ -168,14 +168,19 @@ std::vector<unsigned short> pack_h2(const float *w, int cout, int cin, int kh, i
 // anchored (the smaller kernels of the MTT stems are zero-padded into it).  w32: [32][cin][k1][k1].  K is ordered
 // (dy, ci, dx) with dx padded to DXW = 16 (k1 > 8) or 8 slots and ci padded so that it divides 32/DXW; a K-step of 32 covers
 // 32/DXW (dy, ci) rows.
-// Stream: [K-step][2 splits][2 cout groups][64 lanes][8] fp16 terms of 2^scale_exp * w.
+// Stream: [K-step][3 splits][2 cout groups][64 lanes][8] fp16 terms of 2^scale_exp * w.  THREE terms (33 significand bits: the fp32 weight
+// exactly), not the two of the other layers: the pixels are exact in fp16, so with exact weights every product of the first layer is exact
+// - and this is the layer whose weight error the Luma_Q net amplifies most (raw 0..255 inputs, outputs in the thousands, logits of order
+// 1).  A weight's 2^-23 representation error is the same for every pixel it meets, so it adds up coherently where rounding noise
+// averages out: on the worst block of the 15 840-block campaign two-term stem weights alone cost 5e-4 of the 1e-3 tolerance, three
+// cost 1e-4 (profiles/r04_campaign_config4.txt).
 std::vector<unsigned short> pack_stem_h2(const float *w32, int cin, int k1, int scale_exp)
 {
     const int DXW = k1 > 8 ? 16 : 8, RPK = 32 / DXW;
     const int cinp = (RPK % cin == 0) ? cin : 4;   // chroma QT: 3 planes padded to 4 so a lane's input row advances uniformly
     const int NROW = k1 * cinp, KS = (NROW + RPK - 1) / RPK;
     const float S = std::ldexp(1.f, scale_exp);
-    std::vector<unsigned short> out((size_t)KS * 2 * 2 * 64 * 8, 0);
+    std::vector<unsigned short> out((size_t)KS * 3 * 2 * 64 * 8, 0);
     for (int ks = 0; ks < KS; ++ks)
         for (int nt = 0; nt < 2; ++nt)
             for (int l = 0; l < 64; ++l) {
@@ -190,7 +195,16 @@ std::vector<unsigned short> pack_stem_h2(const float *w32, int cin, int k1, int 
                         if (ci < cin) v[j] = w32[(((size_t)co * cin + ci) * k1 + dy) * k1 + dx] * S;
                     }
                 }
-                split8(v, out.data() + ((((size_t)ks * 2 + 0) * 2 + nt) * 64 + l) * 8, out.data() + ((((size_t)ks * 2 + 1) * 2 + nt) * 64 + l) * 8);
+                unsigned short *o0 = out.data() + ((((size_t)ks * 3 + 0) * 2 + nt) * 64 + l) * 8, *o1 = o0 + 2 * 64 * 8, *o2 = o1 + 2 * 64 * 8;
+                split8(v, o0, o1);
+                float r[8];      // what the two terms leave over: exact in fp32 (both subtractions are), at most 11 significant bits
+                unsigned short dummy[8];
+                for (int j = 0; j < 8; ++j) {
+                    _Float16 h0, h1;
+                    std::memcpy(&h0, o0 + j, 2); std::memcpy(&h1, o1 + j, 2);
+                    r[j] = (v[j] - (float)h0) - (float)h1;
+                }
+                split8(r, o2, dummy);
             }
     return out;
 }

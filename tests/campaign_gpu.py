@@ -42,7 +42,8 @@ def test_full_size_parity(eng, comp, qp):
     hor, ver, q8, d8, qt, bt, dire = eng.infer_postprocess(comp, qp, y, u, v, want_logits=True)
     assert not eng.saturated()
     err = (float(np.abs(qt - oq).max()), float(np.abs(bt - obt).max()), float(np.abs(dire - od).max()))
-    assert max(err) < TOL, "%s QP%d logits off by %s" % (comp, qp, err)
+    strict = os.environ.get("PMP_CAMPAIGN_REPORT_ONLY", "0") != "1"       # report-only: print every figure below before judging (profiles/)
+    assert max(err) < TOL or not strict, "%s QP%d logits off by %s" % (comp, qp, err)
     # (i) post-processing on identical inputs: the device logits through the C oracle - bit-exact, every block
     dh, dv, dq8, dd8 = P.seq_post_process(qt, bt, dire, comp, 1, 64 * N, 64, None)
     exact = np.array_equal(hor, dh) and np.array_equal(ver, dv) and np.array_equal(q8, dq8.astype(np.uint8)) and np.array_equal(d8, dd8)
@@ -73,8 +74,23 @@ def test_full_size_parity(eng, comp, qp):
     e_hip = max(np.abs(qt[si] - rq).max(), np.abs(bt[si] - rbt).max(), np.abs(dire[si] - rd).max())
     e_orc = max(np.abs(oq[si] - rq).max(), np.abs(obt[si] - rbt).max(), np.abs(od[si] - rd).max())
     print("       the 32 worst blocks against fp64-accumulated convolutions: HIP path %.2e, torch fp32 oracle %.2e" % (e_hip, e_orc), flush=True)
+    if not strict:      # the other two datapaths on the same blocks: is the tail the datapath's or the net's?
+        for prec in ("fp32", "bf16x6"):
+            eng.set_precision(prec)
+            q2, b2, d2 = eng.inference_pre_QBD(comp, qp, y, u, v)
+            pb2 = np.maximum(np.abs(q2 - oq).reshape(N, -1).max(1), np.maximum(np.abs(b2 - obt).reshape(N, -1).max(1), np.abs(d2 - od).reshape(N, -1).max(1)))
+            e2 = max(np.abs(q2[si] - rq).max(), np.abs(b2[si] - rbt).max(), np.abs(d2[si] - rd).max())
+            print("       [%s] vs the torch oracle: max %.2e (block %d), p99.9 %.2e, blocks over 1e-3: %d; the same 32 blocks against fp64 accumulation: %.2e"
+                  % (prec, float(pb2.max()), int(np.argmax(pb2)), float(np.quantile(pb2, 0.999)), int((pb2 >= TOL).sum()), e2), flush=True)
+        eng.set_precision(PRECISION)
+        print("       [%s] blocks over 1e-3 against the torch oracle: %d of %d; worst block %d: |HIP - fp64| %.2e, |oracle - fp64| %.2e, |HIP - oracle| %.2e"
+              % (PRECISION, int((per_block >= TOL).sum()), N, worst,
+                 float(max(np.abs(qt[worst] - rq[list(si).index(worst)]).max(), np.abs(bt[worst] - rbt[list(si).index(worst)]).max(), np.abs(dire[worst] - rd[list(si).index(worst)]).max())),
+                 float(max(np.abs(oq[worst] - rq[list(si).index(worst)]).max(), np.abs(obt[worst] - rbt[list(si).index(worst)]).max(), np.abs(od[worst] - rd[list(si).index(worst)]).max())),
+                 float(per_block[worst])), flush=True)
     assert e_hip < TOL
     print("%-6s QP%d  %d blocks: max |logit - oracle| qt %.2e bt %.2e dire %.2e | post-processing of the device logits bit-exact (%d flags) | "
           "end to end %d of %d blocks differ (all among the %d with a value within %.1e of a rounding boundary; %d edge cells) | MTT weights: %s"
           % (comp, qp, N, err[0], err[1], err[2], hor.size + ver.size + q8.size + d8.size, int(bad.sum()), N, int(risky.sum()), margin, cells, src), flush=True)
     assert bad.sum() <= max(8, N // 64)
+    assert max(err) < TOL or not strict
