@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
 // gathered fragment feeds 4-6 MFMAs (two cout groups x the products).  Workgroup = one block; a wave walks batches of 8
 // rows x 16 columns (64 accumulator VGPRs) and streams the weight fragments from L2 once per batch and K-step.
 template <bool LUMA, bool MSBD>
-__global__ __launch_bounds__(256) void stem_mfma_kernel(StemArgs a)
+__global__ __launch_bounds__(256, 2) void stem_mfma_kernel(StemArgs a)   // two workgroups per CU (the luma MTT stem spills 32 registers for it: -6 % on the stems)
 {
     constexpr int S = LUMA ? 68 : 34, P = LUMA ? 4 : 2, PS = S + P, OUT = S - P;   // 72/36 planes, 64/32 outputs
     constexpr int CIN = (LUMA ? 1 : 3) + (MSBD ? 1 : 0);
