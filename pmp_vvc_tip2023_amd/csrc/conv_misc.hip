@@ -244,13 +244,22 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(StemArgs a)   // two 
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const f32x4 bias = *reinterpret_cast<const f32x4 *>(a.bias + nt * 16 + g * 4);
+            // 16-byte stores, as the convolution epilogues (conv_f16x3.hip): one v_permlane16_swap per register turns {rows m, m+1} x {couts 4g..}
+            // into the 8 consecutive channels 8(g>>1).. of row m + (g&1).  This layer is bound by writing its 2.1 GB: 8-byte stores run at 0.6
+            // of the 16-byte rate (MI355X_MICROARCH.md).
 #pragma unroll
-            for (int m = 0; m < RB; ++m) {
-                f32x4 v = acc[m][nt] * inv_scale + bias;
-                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                const size_t o = out_n + (((size_t)nt * OUT + (y0 + m)) * OUT + x0 + xl) * 16 + g * 4;
-                sat_report(a.sat, sat_amax4(0.f, v));
-                store_split2_4(a.out_s3 + o, a.s3_stride, v);
+            for (int m = 0; m < RB; m += 2) {
+                f32x4 v0 = acc[m][nt] * inv_scale + bias, v1 = acc[m + 1][nt] * inv_scale + bias;
+                v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
+                v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
+                sat_report(a.sat, sat_amax4(sat_amax4(0.f, v0), v1));
+                u32x4 p, q;
+                split2_rows(v0, v1, p, q);
+                rows16_swap(p);
+                rows16_swap(q);
+                const size_t o = out_n + (((size_t)nt * OUT + (y0 + m + (g & 1))) * OUT + x0 + xl) * 16 + 8 * (g >> 1);
+                *reinterpret_cast<u32x4 *>(a.out_s3 + o) = p;
+                *reinterpret_cast<u32x4 *>(a.out_s3 + o + a.s3_stride) = q;
             }
         }
     }
