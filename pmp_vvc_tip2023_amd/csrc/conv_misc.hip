@@ -131,23 +131,25 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
 
 // ---- MFMA stem (f16x3 datapath).  The same first layers as stem_kernel, as ONE top-left anchored K1 x K1 convolution with 32
 // outputs on the fp16 matrix cores: pixels (0..255) are exact in fp16, so they need one term; the plane built from the QT
-// logits gets the usual two (x0, x1); weights are THREE scaled fp16 terms (pack_stem_h2: the fp32 weight exactly, so every pixel product
-// is exact - this layer's weight error is the one the Luma_Q net amplifies most).  Products: x0*w2 + x0*w1 + x0*w0 (+ x1*w0
-// for the logit plane).  There is no channel dimension to make a lane's 8 K-values contiguous - they are 8 consecutive
-// pixels of an input row starting at an arbitrary column - so the B fragments are gathered with 2-byte LDS reads; one
-// gathered fragment feeds 4-6 MFMAs (two cout groups x the products).  Workgroup = one block; a wave walks batches of 8
-// rows x 16 columns (64 accumulator VGPRs) and streams the weight fragments from L2 once per batch and K-step.
+// logits gets the usual two (x0, x1); weights are THREE scaled fp16 terms for the pixel planes (pack_stem_h2: the fp32 weight exactly,
+// so every pixel product is exact - this layer's weight error is the one the Luma_Q net amplifies most) and the usual two for the
+// logit plane.  Products: x0*w2 + x0*w1 + x0*w0 (pixels), x0*w1 + x0*w0 + x1*w0 (logits).
+// K order: plane by plane, a K-step = RPS whole kernel rows of one plane (9x9: 3 rows = 27 of the 32 slots, 3 K-steps per plane;
+// 5x5: all 5 rows = 25 slots, one K-step per plane).  There is no channel dimension to make a lane's 8 K-values contiguous, so the B
+// fragments are gathered with 2-byte LDS reads (lane (g, j): slot k = 8g + j -> tap (k / K1, k % K1) of the step's rows); one gathered
+// fragment feeds 6 MFMAs (two cout groups x the products).  The fragments of a batch (output rows m = 0..7) form a sliding window over
+// input rows: the next K-step of a plane needs RPS new ones.  Workgroup = one block; a wave walks batches of 8 rows x 16 columns (64
+// accumulator registers) and streams the weight fragments from L2 once per batch and K-step, one K-step ahead.
+// (Until round 4 a K-step was 2 rows x 16 column slots of ALL planes: 5 K-steps for 81 taps, 9 with the logit plane - 40-50 % more MFMAs.)
 template <bool LUMA, bool MSBD>
-__global__ __launch_bounds__(256, 2) void stem_mfma_kernel(StemArgs a)   // two workgroups per CU (the luma MTT stem spills 32 registers for it: -6 % on the stems)
+__global__ __launch_bounds__(256, 2) void stem_mfma_kernel(StemArgs a)
 {
     constexpr int S = LUMA ? 68 : 34, P = LUMA ? 4 : 2, PS = S + P, OUT = S - P;   // 72/36 planes, 64/32 outputs
     constexpr int CIN = (LUMA ? 1 : 3) + (MSBD ? 1 : 0);
     constexpr int K1 = LUMA ? 9 : 5;
-    constexpr int DXW = K1 > 8 ? 16 : 8, RPK = 32 / DXW;
-    constexpr int CINP = (RPK % CIN == 0) ? CIN : 4;          // chroma QT: 3 planes padded to 4 (zero weights)
-    constexpr int NROW = K1 * CINP, KS = (NROW + RPK - 1) / RPK, STEP = RPK / CINP;
-    static_assert(RPK % CINP == 0 && STEP >= 1, "every lane's input row must advance by the same step per K-step");
-    constexpr int RS = PS + 16;                          // row stride: a fragment may run 15 columns past the last pixel (zero weights there)
+    constexpr int RPS = LUMA ? 3 : 5, KPP = (K1 + RPS - 1) / RPS, KS = CIN * KPP;     // kernel rows per K-step, K-steps per plane
+    static_assert(RPS * K1 <= 32 && KPP * RPS == K1, "a K-step holds whole kernel rows, a plane whole K-steps");
+    constexpr int RS = PS + 16;                          // row stride of the planes in LDS
     constexpr int SEGS = OUT / 16, RB = 8, NBATCH = SEGS * (OUT / RB);
     __shared__ _Float16 h0[CIN * PS * RS + 16];
     __shared__ _Float16 h1[MSBD ? PS * RS + 16 : 8];     // low term of the logit plane
@@ -176,68 +178,83 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(StemArgs a)   // two 
                 qv = a.q[(size_t)n * 64 + ((r - P) / SC) * 8 + (c - P) / SC];
             }
             _Float16 q0, q1;
-            sat_report(a.sat, fabsf(qv));   // checked where it is stored, no register carried through the kernel: at 168 VGPRs this
-            split2(qv, q0, q1);             // kernel keeps three workgroups per CU, at 170 it would be two
+            sat_report(a.sat, fabsf(qv));   // checked where it is stored, no register carried through the kernel
+            split2(qv, q0, q1);
             h0[(CIN - 1) * PS * RS + i] = q0; h1[i] = q1;
         }
     }
     __syncthreads();
 
-    // K rows are (dy, ci) with ci padded to CINP so that every lane's input row advances by the same STEP per K-step:
-    // lane group g reads row  y + ks*STEP + dyoff  of plane ci.  The 8 fragments of a batch (output rows m = 0..7) then form a
-    // sliding window over input rows: a K-step gathers only STEP new fragments (16 or 8 two-byte reads) instead of 8.
     const f16x8 *wl = reinterpret_cast<const f16x8 *>(a.wh) + lane;
     const float inv_scale = a.out_scale;
     const size_t out_n = (size_t)n * 2 * OUT * OUT * 16;
-    const int kr0 = DXW == 16 ? (g >> 1) : g;                 // this lane's K row inside a K-step
-    const int dx0 = DXW == 16 ? 8 * (g & 1) : 0;
-    const int dyoff = kr0 / CINP, ci = min(kr0 - dyoff * CINP, CIN - 1);   // padded channel: zero weights, any valid plane
-    const bool qrow = MSBD && (kr0 - dyoff * CINP) == CIN - 1;
-    auto gather = [&](const _Float16 *p) {
+    int eo[8];      // element offsets of this lane's 8 K slots inside a fragment: tap (dy, dx) of the K-step's rows (slots past RPS * K1: zero weights, any valid address)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int kk = 8 * g + j;
+        eo[j] = min(kk / K1, RPS - 1) * RS + kk % K1;
+    }
+    auto gather = [&](const _Float16 *p) __attribute__((always_inline)) {
         f16x8 v;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = p[j];
+        for (int j = 0; j < 8; ++j) v[j] = p[eo[j]];
         return v;
     };
     for (int b = wave; b < NBATCH; b += 4) {
         const int seg = b % SEGS, y0 = (b / SEGS) * RB, x0 = seg * 16;
-        // row index clamped: the window runs up to STEP-1 rows past the last row a real tap needs (zero weights there)
-        const _Float16 *base = h0 + (ci * PS) * RS + x0 + xl + dx0;
-        const _Float16 *base1 = h1 + x0 + xl + dx0;
-        auto row = [&](int p) { return min(y0 + dyoff + p, PS - 1) * RS; };
         f32x4 acc[RB][2];
         f16x8 win[RB], win1[MSBD ? RB : 1];
 #pragma unroll
-        for (int m = 0; m < RB; ++m) {
-            acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            win[m] = gather(base + row(m));
-            if (MSBD) win1[m] = qrow ? gather(base1 + row(m)) : (f16x8)(_Float16)0.f;
-        }
+        for (int m = 0; m < RB; ++m) { acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        // weight fragments [w0 | w1 | w2][nt] of a K-step, requested one K-step ahead; the fences keep hipcc from hoisting the requests of
+        // all KS steps to the top of the batch (KS x 24 registers)
+        f16x8 wq[2][6];
+        auto wload = [&](int ks, bool third) __attribute__((always_inline)) {
+            const f16x8 *wk = wl + (size_t)ks * (3 * 2 * 64);
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                if (i < 4 || third) wq[ks & 1][i] = wk[i * 64];
+        };
+        wload(0, true);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const f16x8 *wk = wl + (size_t)ks * (3 * 2 * 64);
-            const f16x8 w00 = wk[0], w01 = wk[64], w10 = wk[128], w11 = wk[192], w20 = wk[256], w21 = wk[320];   // [split][nt]
+            constexpr int dummy = 0; (void)dummy;
+            const int plane = ks / KPP, s = ks % KPP, r0 = s * RPS;
+            const bool isq = MSBD && plane == CIN - 1;
+            const _Float16 *base = h0 + (plane * PS + y0) * RS + x0 + xl;
+            const _Float16 *base1 = h1 + y0 * RS + x0 + xl;
+            if (s == 0) {      // a new plane: the whole window
+#pragma unroll
+                for (int m = 0; m < RB; ++m) {
+                    win[m] = gather(base + m * RS);
+                    if (isq) win1[m] = gather(base1 + m * RS);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 1 < KS) wload(ks + 1, !(MSBD && (ks + 1) / KPP == CIN - 1));
+            __builtin_amdgcn_sched_barrier(0);
+            const f16x8 w00 = wq[ks & 1][0], w01 = wq[ks & 1][1], w10 = wq[ks & 1][2], w11 = wq[ks & 1][3];
 #pragma unroll
             for (int m = 0; m < RB; ++m) {
-                const f16x8 bx = win[(m + ks * STEP) & 7];
-                acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w20, bx, acc[m][0], 0, 0, 0);     // smallest terms first
-                acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w21, bx, acc[m][1], 0, 0, 0);
+                const f16x8 bx = win[(m + r0) & (RB - 1)];
+                if (!isq) {
+                    const f16x8 w20 = wq[ks & 1][4], w21 = wq[ks & 1][5];
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w20, bx, acc[m][0], 0, 0, 0);     // smallest terms first
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w21, bx, acc[m][1], 0, 0, 0);
+                }
                 acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w10, bx, acc[m][0], 0, 0, 0);
                 acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w11, bx, acc[m][1], 0, 0, 0);
                 acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w00, bx, acc[m][0], 0, 0, 0);
                 acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01, bx, acc[m][1], 0, 0, 0);
-                if (MSBD) {
-                    const f16x8 b1 = win1[(m + ks * STEP) & 7];
+                if (isq) {
+                    const f16x8 b1 = win1[(m + r0) & (RB - 1)];
                     acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w00, b1, acc[m][0], 0, 0, 0);
                     acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01, b1, acc[m][1], 0, 0, 0);
                 }
-            }
-            if (ks + 1 < KS) {   // slide the window: positions 8 + ks*STEP .. replace the oldest STEP slots
-#pragma unroll
-                for (int t = 0; t < STEP; ++t) {
-                    const int p = RB + ks * STEP + t;
-                    win[p & 7] = gather(base + row(p));
-                    if (MSBD) win1[p & 7] = qrow ? gather(base1 + row(p)) : (f16x8)(_Float16)0.f;
+                if (s + 1 < KPP && m < RPS) {   // slide the window: input row RB + r0 + m takes the slot this row just left
+                    const int p = RB + r0 + m;
+                    win[p & (RB - 1)] = gather(base + p * RS);
+                    if (isq) win1[p & (RB - 1)] = gather(base1 + p * RS);
                 }
             }
         }
@@ -245,8 +262,7 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(StemArgs a)   // two 
         for (int nt = 0; nt < 2; ++nt) {
             const f32x4 bias = *reinterpret_cast<const f32x4 *>(a.bias + nt * 16 + g * 4);
             // 16-byte stores, as the convolution epilogues (conv_f16x3.hip): one v_permlane16_swap per register turns {rows m, m+1} x {couts 4g..}
-            // into the 8 consecutive channels 8(g>>1).. of row m + (g&1).  This layer is bound by writing its 2.1 GB: 8-byte stores run at 0.6
-            // of the 16-byte rate (MI355X_MICROARCH.md).
+            // into the 8 consecutive channels 8(g>>1).. of row m + (g&1)
 #pragma unroll
             for (int m = 0; m < RB; m += 2) {
                 f32x4 v0 = acc[m][nt] * inv_scale + bias, v1 = acc[m + 1][nt] * inv_scale + bias;

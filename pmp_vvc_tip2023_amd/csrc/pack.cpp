@@ -165,9 +165,9 @@ std::vector<unsigned short> pack_h2(const float *w, int cout, int cin, int kh, i
 }
 
 // Stem weights for the MFMA stem (conv_misc.hip: stem_mfma_kernel): ONE k1 x k1 convolution with 32 outputs, top-left
-// anchored (the smaller kernels of the MTT stems are zero-padded into it).  w32: [32][cin][k1][k1].  K is ordered
-// (dy, ci, dx) with dx padded to DXW = 16 (k1 > 8) or 8 slots and ci padded so that it divides 32/DXW; a K-step of 32 covers
-// 32/DXW (dy, ci) rows.
+// anchored (the smaller kernels of the MTT stems are zero-padded into it).  w32: [32][cin][k1][k1].  K is ordered plane by
+// plane; a K-step of 32 slots holds RPS whole kernel rows of one plane (k1 = 9: 3 rows = 27 slots; k1 = 5: 5 rows = 25 slots), slot
+// k = (dy - r0) * k1 + dx, the rest zero.
 // Stream: [K-step][3 splits][2 cout groups][64 lanes][8] fp16 terms of 2^scale_exp * w.  THREE terms (33 significand bits: the fp32 weight
 // exactly), not the two of the other layers: the pixels are exact in fp16, so with exact weights every product of the first layer is exact
 // - and this is the layer whose weight error the Luma_Q net amplifies most (raw 0..255 inputs, outputs in the thousands, logits of order
@@ -176,24 +176,17 @@ std::vector<unsigned short> pack_h2(const float *w, int cout, int cin, int kh, i
 // cost 1e-4 (profiles/r04_campaign_config4.txt).
 std::vector<unsigned short> pack_stem_h2(const float *w32, int cin, int k1, int scale_exp)
 {
-    const int DXW = k1 > 8 ? 16 : 8, RPK = 32 / DXW;
-    const int cinp = (RPK % cin == 0) ? cin : 4;   // chroma QT: 3 planes padded to 4 so a lane's input row advances uniformly
-    const int NROW = k1 * cinp, KS = (NROW + RPK - 1) / RPK;
+    const int RPS = k1 > 8 ? 3 : 5, KPP = (k1 + RPS - 1) / RPS, KS = cin * KPP;   // kernel rows per K-step, K-steps per plane (stem_mfma_kernel)
     const float S = std::ldexp(1.f, scale_exp);
     std::vector<unsigned short> out((size_t)KS * 3 * 2 * 64 * 8, 0);
     for (int ks = 0; ks < KS; ++ks)
         for (int nt = 0; nt < 2; ++nt)
             for (int l = 0; l < 64; ++l) {
-                const int g = l >> 4, co = nt * 16 + (l & 15);
-                const int kr = DXW == 16 ? RPK * ks + (g >> 1) : RPK * ks + g;
+                const int g = l >> 4, co = nt * 16 + (l & 15), ci = ks / KPP, r0 = (ks % KPP) * RPS;
                 float v[8];
                 for (int j = 0; j < 8; ++j) {
-                    const int dx = (DXW == 16 ? 8 * (g & 1) : 0) + j;
-                    v[j] = 0.f;
-                    if (kr < NROW && dx < k1) {
-                        const int dy = kr / cinp, ci = kr % cinp;
-                        if (ci < cin) v[j] = w32[(((size_t)co * cin + ci) * k1 + dy) * k1 + dx] * S;
-                    }
+                    const int kk = 8 * g + j, dyl = kk / k1, dx = kk % k1, dy = r0 + dyl;
+                    v[j] = (dyl < RPS && dy < k1) ? w32[(((size_t)co * cin + ci) * k1 + dy) * k1 + dx] * S : 0.f;
                 }
                 unsigned short *o0 = out.data() + ((((size_t)ks * 3 + 0) * 2 + nt) * 64 + l) * 8, *o1 = o0 + 2 * 64 * 8, *o2 = o1 + 2 * 64 * 8;
                 split8(v, o0, o1);
