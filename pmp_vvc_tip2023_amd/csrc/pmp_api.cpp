@@ -29,7 +29,8 @@ int hip_fail(pmp_ctx *c, hipError_t e, const char *what)
 // (tools/probe/malloc_probe.py: the freed VRAM is still being cleared); a host that destroys a context and creates the next one -
 // one per sequence, one per encoder instance - would pay that for its 10 GB activation workspace every time.  pmp_destroy therefore
 // PARKS the workspace (one buffer per device, the larger one wins) and the next context on that device takes it over; pmp_trim()
-// gives parked memory back to the driver.
+// gives parked memory back to the driver.  PMP_PARK_WORKSPACE=0 in the environment turns parking off (pmp_destroy then frees everything:
+// for a host that destroys its context to hand the VRAM to another library and cannot call pmp_trim).
 namespace {
 std::mutex g_park_mutex;
 std::map<int, DevBuf> g_parked;   // device -> buffer
@@ -38,6 +39,8 @@ std::map<int, DevBuf> g_parked;   // device -> buffer
 static void park_workspace(int device, DevBuf &b)
 {
     if (!b.p) return;
+    const char *env = std::getenv("PMP_PARK_WORKSPACE");
+    if (env && env[0] == '0' && !env[1]) { hipFree(b.p); b = DevBuf(); return; }
     std::lock_guard<std::mutex> lk(g_park_mutex);
     DevBuf &slot = g_parked[device];
     if (slot.cap >= b.cap) { hipFree(b.p); }

@@ -178,6 +178,33 @@ def test_parked_workspace_is_reused_and_trimmed(g1):
     assert e2.lib.pmp_trim() == 0
 
 
+def test_parking_can_be_turned_off(g1, monkeypatch):
+    """PMP_PARK_WORKSPACE=0: pmp_destroy returns the whole workspace to the driver (a host that hands the VRAM to another library and
+    cannot call pmp_trim); by default the 320 MB of this pass stay parked until pmp_trim."""
+    import torch
+    from pmp_vvc_tip2023_amd import engine
+    y = np.concatenate([g1["block_y"]] * 8)
+
+    def held_after_destroy():
+        e2 = engine.Engine(0, allow_synthetic_mtt=True)
+        e2.lib.pmp_trim()
+        torch.cuda.synchronize(0)
+        before = torch.cuda.mem_get_info(0)[0]
+        try:
+            e2.inference_pre_QBD("Luma", 22, y)
+        finally:
+            e2.close()
+        return before - torch.cuda.mem_get_info(0)[0], e2.lib
+
+    held, lib = held_after_destroy()
+    assert held > 200 * 2 ** 20
+    assert lib.pmp_trim() == 0
+    monkeypatch.setenv("PMP_PARK_WORKSPACE", "0")
+    held, lib = held_after_destroy()
+    assert held < 64 * 2 ** 20
+    assert lib.pmp_trim() == 0
+
+
 def test_default_chunk_boundary(eng):
     """More blocks than one library pass (default chunk 4096): the ragged second pass gives what a call on those blocks alone gives."""
     from pmp_vvc_tip2023_amd import synth
