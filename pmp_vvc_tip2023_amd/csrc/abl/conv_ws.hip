@@ -5,7 +5,8 @@
 // weights of ITS 16 output channels for all 18 K-steps in registers (18 x 2 terms x 4 = 144 registers); the K-loop then has no
 // vector-memory operation at all - pixel fragments from LDS, weights from registers - and the halo image of the NEXT tile arrives by
 // LDS-DMA (global_load_lds_dwordx4, no staging registers, no LDS stores) while this one is computed.
-//   tile      16 x 8 output pixels, all 64 input channels resident: 4 groups x 2 planes x 10 x 18 halo pixels x 32 B = 46 KB, two buffers
+//   tile      16 x 8 output pixels, all 64 input channels resident: 4 groups x 2 planes x 10 x 18 halo pixels x 32 B = 46 KB (48 KB reserved),
+//             two or three buffers (one or two tiles of lookahead)
 //   wave      cout group (wave & 3) x row half (wave >> 2): 4 rows x 16 px x 16 couts = 16 accumulator registers; the two waves of a SIMD
 //             share a cout group, i.e. hold the same weights.  Every pixel fragment feeds ONE output group (3 MFMAs): 0.67 ds_read_b128
 //             per MFMA, twice the product kernel's LDS rate - the price of weights that never move.
@@ -30,10 +31,10 @@ struct ConvWsArgs {
 namespace {
 
 constexpr int WS_TH = 8, WS_HR = WS_TH + 2, WS_HC = 18;
-constexpr int WS_ROW = WS_HC * 32, WS_PLN = WS_HR * WS_ROW, WS_GRP = 2 * WS_PLN, WS_IMG = 4 * WS_GRP;      // 576, 5760, 11 520, 46 080 B
-constexpr int WS_PIECES = WS_IMG / 16;              // 2880 pieces of 16 B
-constexpr int WS_NDMA = 6;                          // DMA instructions per lane and tile: 8 waves x 6 x 64 = 3072 pieces (192 dummies)
-constexpr int WS_BUF = WS_NDMA * 8 * 64 * 16;       // 49 152 B reserved per buffer
+constexpr int WS_NDMA = 6;                          // DMA instructions per lane and tile: wave w fills image (group w >> 1, plane w & 1), 6 x 64 pieces of 16 B
+constexpr int WS_ROW = WS_HC * 32, WS_PLN = WS_NDMA * 1024, WS_GRP = 2 * WS_PLN;      // 576 B; a plane's 5760 B padded to 6 KB (24 dummy pieces)
+constexpr int WS_PIECES = WS_HR * WS_HC * 2;        // 360 valid pieces per plane image
+constexpr int WS_BUF = 8 * WS_PLN;                  // 49 152 B per buffer
 
 // pack_h2's K-step list for 9 taps over 4 groups (chain16_dev.h: c16_step_off<9, 4>) on this tile's image geometry
 __device__ __forceinline__ constexpr int ws_step_off(int st, int half)
@@ -77,23 +78,27 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvWsArgs a)
         tx = r / tiles_y;
         ty = r - tx * tiles_y;
     };
-    // halo image of tile t -> buffer `buf`: piece i = [group][plane][row][col][half], 16 B each; out-of-image and dummy pieces from the zero line
+    // halo image of tile t -> buffer `buf`: wave w moves plane w & 1 of group w >> 1, piece j = k * 64 + lane = [row][col][half]; what
+    // depends on the lane is worked out once (offset of the piece relative to the tile's origin, which image borders it touches), what
+    // depends on the tile is scalar: ~6 vector instructions per piece
+    int rel[WS_NDMA];
+    unsigned pflags = 0;         // 5 bits per piece: halo row 0, row 9, column 0, column 17, dummy piece
+#pragma unroll
+    for (int k = 0; k < WS_NDMA; ++k) {
+        const int j = k * 64 + lane, jc = min(j, WS_PIECES - 1), pix = jc >> 1, half = jc & 1, row = pix / WS_HC, col = pix - row * WS_HC;
+        rel[k] = (((row - 1) * W + (col - 1)) * 16 + half * 8) * 2;
+        pflags |= (unsigned)((row == 0) | ((row == WS_HR - 1) << 1) | ((col == 0) << 2) | ((col == WS_HC - 1) << 3) | ((j >= WS_PIECES) << 4)) << (5 * k);
+    }
     auto dma_tile = [&](int t, int buf) __attribute__((always_inline)) {
         int n, ty, tx;
         coords(t, n, ty, tx);
-        const unsigned short *xg = a.x + (size_t)n * 4 * grp_sz;
+        const char *base = reinterpret_cast<const char *>(a.x + (size_t)(wave & 1) * a.x_stride + ((size_t)n * 4 + (wave >> 1)) * grp_sz +
+                                                         ((size_t)(ty * WS_TH) * W + tx * 16) * 16);
+        const unsigned border = (ty == 0 ? 1u : 0u) | (ty == tiles_y - 1 ? 2u : 0u) | (tx == 0 ? 4u : 0u) | (tx == (W >> 4) - 1 ? 8u : 0u) | 16u;
 #pragma unroll
         for (int k = 0; k < WS_NDMA; ++k) {
-            int ln = lane;
-            asm volatile("" : "+v"(ln));        // opaque: the address arithmetic stays where the piece is issued
-            const int i = (k * 8 + wave) * 64 + ln, ic = min(i, WS_PIECES - 1);
-            const int cb = ic / 720, r = ic - cb * 720, sp = r / 360, j = r - sp * 360, pix = j >> 1, half = j & 1;
-            const int row = pix / WS_HC, col = pix - row * WS_HC;
-            const int gy = ty * WS_TH + row - 1, gx = tx * 16 + col - 1;
-            const bool in_image = i < WS_PIECES && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            const size_t off = (size_t)sp * a.x_stride + (size_t)cb * grp_sz + ((size_t)(gy * W + gx) * 16 + half * 8);
-            const void *src = in_image ? (const void *)(xg + off) : a.zeros;
-            ws_dma16(src, lds_base + (unsigned)(buf * WS_BUF + (k * 8 + wave) * 1024));
+            const void *src = ((pflags >> (5 * k)) & border) ? a.zeros : (const void *)(base + rel[k]);
+            ws_dma16(src, lds_base + (unsigned)(buf * WS_BUF + wave * WS_PLN + k * 1024));
         }
     };
 
@@ -107,17 +112,20 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvWsArgs a)
             wq[st][1] = wl[(size_t)st * (2 * 4 * 64) + 4 * 64];
         }
     }
-    if (t0 < t1) dma_tile(t0, 0);
+    constexpr int LA = NBUF - 1;      // tiles of lookahead
+#pragma unroll
+    for (int i = 0; i < LA; ++i)
+        if (t0 + i < t1) dma_tile(t0 + i, i);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
     const int lane_off = ((rh * 4) * WS_HC + xl) * 32 + (g & 1) * 16;
     const bool hi = (g >> 1) != 0;
 
+    int buf = 0, nbuf = LA % NBUF;        // buffer of tile t, buffer of tile t + LA
     for (int t = t0; t < t1; ++t) {
-        const int buf = (t - t0) % NBUF;
         int n, ty, tx;
         coords(t, n, ty, tx);
-        if (t + 1 < t1 && (!(ABL & 1))) dma_tile(t + 1, (t + 1 - t0) % NBUF);
+        if (t + LA < t1 && (!(ABL & 1))) dma_tile(t + LA, nbuf);
         // this wave's output rows: element offset of (row 0, cout 4g) in a [n][4][H][W][16] tensor
         const size_t o0 = (((size_t)n * 4 + ct) * H + (ty * WS_TH + rh * 4)) * W * 16 + (size_t)(tx * 16 + xl) * 16 + g * 4;
         u32x2_t ra[4], rb[4];
@@ -163,8 +171,10 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvWsArgs a)
             for (int m = 0; m < 2; ++m) acc[h * 2 + m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, x1[m], acc[h * 2 + m], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        // the next tile's image has landed (requested a K-loop ago); the stores below are not waited for
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the next tile's image has landed: everything older than this iteration's requests (the image of tile t + LA, the residual) is
+        // complete - loads return in order.  The stores below are not waited for.
+        if (LA > 1) asm volatile("s_waitcnt vmcnt(%c0)" ::"i"(WS_NDMA + (RES ? 8 : 0)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
         auto epilogue = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -191,6 +201,8 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvWsArgs a)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             epilogue();
         }
+        buf = buf + 1 == NBUF ? 0 : buf + 1;
+        nbuf = nbuf + 1 == NBUF ? 0 : nbuf + 1;
     }
     sat_report(a.sat, amax);
 }

@@ -25,16 +25,16 @@ def main():
     flop = 2.0 * n * size * size * 64 * 64 * 9
     names = {0: "exact build", 1: "no halo DMA after the first tile", 2: "no MFMAs", 4: "no epilogue arithmetic", 8: "no residual loads",
              6: "no MFMAs, no epilogue arithmetic", 7: "DMA-less, MFMA-less, epilogue-less", 12: "no epilogue arithmetic, no residual", 13: "K-loops only (no DMA, no epilogue arithmetic, no residual)"}
-    cases = [(1, 0, 0), (1, 0, 0), (0, 0, 0)] if not once else [(1, 0, 0)]
+    nb = int(os.environ.get("WS_NBUF", "3"))
+    cases = [(1, 0, 0, 2), (1, 0, 0, 3), (1, 0, 0, 2), (1, 0, 0, 3), (0, 0, 0, 2), (0, 0, 0, 3)] if not once else [(1, 0, 0, nb)]
     if not once:
-        cases += [(1, a, 0) for a in (1, 2, 4, 8, 12, 13, 6, 7)]
-        cases += [(1, 0, g) for g in (128, 512)]
-    for res, abl, grid in cases:
+        cases += [(1, a, 0, nb) for a in (1, 2, 4, 8, 12, 13, 6, 7)]
+    for res, abl, grid, nbuf in cases:
         tp, tf, md, mr, bad = C.c_double(), C.c_double(), C.c_double(), C.c_double(), C.c_int64()
-        rc = f(ctx, n, size, size, res, 10, 3, abl, 2, grid, C.byref(tp), C.byref(tf), C.byref(bad), C.byref(md), C.byref(mr))
+        rc = f(ctx, n, size, size, res, 10, 3, abl, nbuf, grid, C.byref(tp), C.byref(tf), C.byref(bad), C.byref(md), C.byref(mr))
         assert rc == 0, lib.pmp_last_error(ctx)
-        print("%4d blocks %dx%d res %d grid %3s abl %2d %-62s product %.3f ms (%.0f TF)   weight-stationary %.3f ms (%.0f TF)  %+.1f %%   exact build: %d mismatching elements, max |diff| %.3g of %.3g"
-              % (n, size, size, res, grid or "CUs", abl, names[abl], tp.value, flop / tp.value / 1e9, tf.value, flop / tf.value / 1e9, (tf.value / tp.value - 1) * 100, bad.value, md.value, mr.value), flush=True)
+        print("%4d blocks %dx%d res %d bufs %d abl %2d %-62s product %.3f ms (%.0f TF)   weight-stationary %.3f ms (%.0f TF)  %+.1f %%   exact build: %d mismatching elements, max |diff| %.3g of %.3g"
+              % (n, size, size, res, nbuf, abl, names[abl], tp.value, flop / tp.value / 1e9, tf.value, flop / tf.value / 1e9, (tf.value / tp.value - 1) * 100, bad.value, md.value, mr.value), flush=True)
     lib.pmp_destroy(ctx)
 
 
