@@ -52,3 +52,37 @@ for rnd in range(2):
         print("round %d: %d streams x %d blocks: %.2f ms (%+.1f %%)  records identical: %s" % (rnd, k, n // k, tk, 100 * (tk - t1) / t1, np.array_equal(r1, rk)), flush=True)
         for e in es:
             e.close()
+
+# Round 4: the same two streams DE-PHASED - no synchronisation between repetitions, stream B starts behind a pass on a fraction of its blocks,
+# so that one half's QT net (3x3 layers: HBM-heavy) tends to run beside the other half's MTT net (5x5 layers: MFMA-heavy).
+if os.environ.get("PMP_TWO_STREAM_OFFSET", "1") == "1":
+    reps = 8
+    es = make(2)
+    parts = [(0, n // 2), (n // 2, n)]
+    recs = [torch.empty((hi - lo, 1344), dtype=torch.uint8, device=dev) for lo, hi in parts]
+
+    def enq(e, lo, hi, r):
+        e.infer_postprocess_records_device(comp, 22, d_y[lo:hi].data_ptr(), d_u[lo:hi].data_ptr() if chroma else None,
+                                           d_v[lo:hi].data_ptr() if chroma else None, hi - lo, r.data_ptr())
+    for frac in (0.0, 0.25, 0.5):
+        for rnd in range(2):
+            for e, (lo, hi), r in zip(es, parts, recs):
+                enq(e, lo, hi, r)
+            for e in es:
+                e.synchronize()
+            t0 = time.perf_counter()
+            if frac:
+                lo, hi = parts[1]
+                enq(es[1], lo, lo + int((hi - lo) * frac), recs[1])
+            for _ in range(reps):
+                for e, (lo, hi), r in zip(es, parts, recs):
+                    enq(e, lo, hi, r)
+            for e in es:
+                e.synchronize()
+            dt = (time.perf_counter() - t0) * 1e3
+            t1s, _ = run(one, [(0, n)])
+            work = reps + frac / 2
+            print("de-phased by %.2f of a half pass, no sync between %d repetitions: %.2f ms per %d blocks (one stream now: %.2f ms, %+.1f %%)"
+                  % (frac, reps, dt / work, n, t1s, 100 * (dt / work - t1s) / t1s), flush=True)
+    for e in es:
+        e.close()
