@@ -249,7 +249,7 @@ __device__ __forceinline__ void expand(Search &s)
 // Four waves per block: the QT leaves under the four 32x32 quadrants are independent searches writing disjoint cells, so wave
 // w takes the nodes of quadrant w (a block that is one 64x64 leaf is searched by wave 0 alone).  Every wave keeps the whole
 // block's maps - the search code is the single-wave one - and has its own pairwise-sum scratch.
-__global__ __launch_bounds__(256) void postprocess_kernel(const float *__restrict__ qt, const float *__restrict__ bt,
+__global__ __launch_bounds__(256, 4) void postprocess_kernel(const float *__restrict__ qt, const float *__restrict__ bt,
                                                           const float *__restrict__ dire, int64_t N, int cf,
                                                           uint8_t *__restrict__ hor_o, uint8_t *__restrict__ ver_o,
                                                           uint8_t *__restrict__ qt_o, int8_t *__restrict__ dire_o,
