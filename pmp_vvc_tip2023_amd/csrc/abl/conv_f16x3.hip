@@ -464,6 +464,10 @@ __global__ __launch_bounds__(W8 == 1 ? 512 : 256, W8 == 1 ? 4 : (NT == 4 && !LEA
     if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
     const int n0 = bid / tiles, t = bid - n0 * tiles, ty = t / tiles_x, tx = t - ty * tiles_x;
     const int n = (ABL & 64) ? 0 : n0;   // timing-only build: every block's addresses collapse onto block 0 (L2-resident working set)
+    // ABL 512: only the READS collapse onto block 0 (input and residual L2-resident, the output still goes to its own addresses): what a
+    // layer costs when its inputs come from cache and only its output travels to HBM
+    const int n_in = (ABL & 512) ? 0 : n;
+    if ((ABL & 512) && a.res) a.res -= (size_t)n0 * NT * a.H * a.W * 16;
     typedef WaveTile<NT, W8> WT;
     constexpr int RW = WT::RW, CW = WT::CW;
 
@@ -476,8 +480,8 @@ __global__ __launch_bounds__(W8 == 1 ? 512 : 256, W8 == 1 ? 4 : (NT == 4 && !LEA
     const unsigned long long t_begin = (ABL & 128) ? h2_stamp() : 0;
     {
         H2Carry<KH, KW, NT, W8> carry;
-        h2_accumulate<KH, KW, NT, ABL, false, LEAN, W8>(a.x, a.x_stride, a.w, a.Cin, a.H, a.W, n, ty, tx, lds, acc,
-                                       a.abl.dbg ? a.abl.dbg + (size_t)blockIdx.x * 16 : nullptr, carry, true, n, ty, tx);
+        h2_accumulate<KH, KW, NT, ABL, false, LEAN, W8>(a.x, a.x_stride, a.w, a.Cin, a.H, a.W, n_in, ty, tx, lds, acc,
+                                       a.abl.dbg ? a.abl.dbg + (size_t)blockIdx.x * 16 : nullptr, carry, true, n_in, ty, tx);
     }
     const unsigned long long t_acc = (ABL & 128) ? h2_stamp() : 0;
     if (SC == 2) {
@@ -528,6 +532,85 @@ __global__ __launch_bounds__(256, LEAN ? 3 : 2) void conv_h2_persist_kernel(Conv
         first = false;
         h2_epilogue<NT, ABL>(a, acc, n, ty, tx);
     }
+}
+
+// ---- layer-pipelined persistent form of a TRUNK of 3x3 64->64 layers (round 4, tools/trunk_probe.py).  With one launch per layer every
+// tensor of the trunk crosses HBM two or three times (out, in, residual): 3.2-3.7 GB per 1024-block launch at 3.7-4.1 TB/s.  With its
+// reads served from cache the same kernel runs 10-16 % faster (ABL 512: 0.806 -> 0.680 ms with residual, 0.718 -> 0.649 without).  This
+// kernel tries to get there for real: resident workgroups take tiles (layer, block, tile) from ONE work counter in wave-front order -
+// at block step s layer l works on block s - l * D - so that a layer's output block is consumed by the next layer ~D * L * 16 tiles
+// later, while it is still in the 256 MB Infinity Cache.  A tile of layer l waits until all 16 tiles of block b of layer l - 1 are
+// published (a counter per layer and block, release / acquire at agent scope); dependencies only point at smaller work ids, so the
+// scheme cannot deadlock whatever the residency.  The tile body is conv_h2_kernel's: bit-identical results.
+struct TrunkPipeArgs {
+    const ConvX6Args *layers;     // L descriptors in global memory: same N, H, W; 3x3, Cin = Cout = 64, no shortcut source
+    int L, N, D;                  // layers, blocks, delay in blocks between consecutive layers
+    unsigned *work, *done, *err;  // zeroed: work counter, tile counters [L][N], error flag (spin limit hit)
+};
+
+// SYNC (timing-only switches, results may be wrong): 1 no release fence, 2 relaxed flag loads (no cache invalidate), 4 no waiting at all
+template <int SYNC>
+__global__ __launch_bounds__(256, 3) void trunk_pipe_kernel(TrunkPipeArgs p)
+{
+    typedef GeoH<3, 3> G;
+    __shared__ u32x4 lds[2 * G::BUF];
+    __shared__ unsigned s_wk;
+    typedef WaveTile<4> WT;
+    constexpr int RW = WT::RW, CW = WT::CW;
+    const int tiles_x = p.layers[0].W >> 4, T = tiles_x * (p.layers[0].H >> 4), per_step = p.L * T;
+    const unsigned total = (unsigned)(p.N + (p.L - 1) * p.D) * (unsigned)per_step;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_wk = atomicAdd(p.work, 1u);
+        __syncthreads();
+        const unsigned wk = s_wk;
+        if (wk >= total) break;
+        const int s = (int)(wk / (unsigned)per_step), r = (int)(wk - (unsigned)s * (unsigned)per_step), l = r / T, t = r - l * T, b = s - l * p.D;
+        if (b < 0 || b >= p.N) continue;
+        if (l > 0 && !(SYNC & 4)) {
+            if (threadIdx.x == 0) {
+                unsigned *flag = p.done + (size_t)(l - 1) * p.N + b;
+                unsigned spins = 0;
+                while (((SYNC & 2) ? __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                   : __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < (unsigned)T) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > (1u << 22)) { atomicExch(p.err, 1u); break; }      // never hang the box: give up, report
+                }
+            }
+            __syncthreads();
+        }
+        const ConvX6Args &a = p.layers[l];       // (a reference: the fields are fetched where they are used - a local copy costs 40 SGPRs for the whole tile)
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        f32x4 acc[RW][CW];
+#pragma unroll
+        for (int m = 0; m < RW; ++m)
+#pragma unroll
+            for (int nt = 0; nt < CW; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        {
+            H2Carry<3, 3, 4> carry;
+            h2_accumulate<3, 3, 4, 0, false, true>(a.x, a.x_stride, a.w, 64, a.H, a.W, b, ty, tx, lds, acc, nullptr, carry, true, b, ty, tx);
+        }
+        h2_epilogue<4, 0>(a, acc, b, ty, tx);
+        __syncthreads();          // every wave's stores are complete (vmcnt(0) in front of the barrier)
+        if (threadIdx.x == 0) {
+            if (!(SYNC & 1)) __threadfence();      // ... and visible at agent scope before the tile is published
+            atomicAdd(p.done + (size_t)l * p.N + b, 1u);
+        }
+    }
+}
+
+hipError_t launch_trunk_pipe(hipStream_t s, const TrunkPipeArgs &p, int grid, int sync)
+{
+    if (p.L < 1 || p.N < 1 || p.D < 1 || grid < 1) return hipErrorInvalidValue;
+    switch (sync) {
+    case 0: hipLaunchKernelGGL((trunk_pipe_kernel<0>), dim3(grid), dim3(256), 0, s, p); break;
+    case 1: hipLaunchKernelGGL((trunk_pipe_kernel<1>), dim3(grid), dim3(256), 0, s, p); break;
+    case 2: hipLaunchKernelGGL((trunk_pipe_kernel<2>), dim3(grid), dim3(256), 0, s, p); break;
+    case 3: hipLaunchKernelGGL((trunk_pipe_kernel<3>), dim3(grid), dim3(256), 0, s, p); break;
+    case 7: hipLaunchKernelGGL((trunk_pipe_kernel<7>), dim3(grid), dim3(256), 0, s, p); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 // ---- loader-wave form (Cout = 64, no shortcut source, even number of channel groups; opt-in, pmp_debug_set_conv_variant(6)).
@@ -795,6 +878,8 @@ static bool launch_h2_variant(hipStream_t s, const ConvX6Args &a, int grid)
             case 128: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 128>), dim3(grid), dim3(256), 0, s, a); return true;
             case 256: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 256>), dim3(grid), dim3(256), 0, s, a); return true;
             case 1152: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 128, true>), dim3(grid), dim3(256), 0, s, a); return true;   // stamps of the default (three-workgroup) form
+            case 1088: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 64, true>), dim3(grid), dim3(256), 0, s, a); return true;    // three-workgroup form, every address on block 0
+            case 1536: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 512, true>), dim3(grid), dim3(256), 0, s, a); return true;   // three-workgroup form, reads on block 0, writes where they belong
             case 129: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 129>), dim3(grid), dim3(256), 0, s, a); return true;
             case 130: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 130>), dim3(grid), dim3(256), 0, s, a); return true;
             case 131: hipLaunchKernelGGL((conv_h2_kernel<3, 3, 4, false, 131>), dim3(grid), dim3(256), 0, s, a); return true;

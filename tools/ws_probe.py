@@ -27,7 +27,7 @@ def main():
              6: "no MFMAs, no epilogue arithmetic", 7: "DMA-less, MFMA-less, epilogue-less", 12: "no epilogue arithmetic, no residual", 13: "K-loops only (no DMA, no epilogue arithmetic, no residual)"}
     nb = int(os.environ.get("WS_NBUF", "3"))
     cases = [(1, 0, 0, 2), (1, 0, 0, 3), (1, 0, 0, 2), (1, 0, 0, 3), (0, 0, 0, 2), (0, 0, 0, 3)] if not once else [(1, 0, 0, nb)]
-    if not once:
+    if not once and os.environ.get("WS_ONLY_EXACT", "0") != "1":
         cases += [(1, a, 0, nb) for a in (1, 2, 4, 8, 12, 13, 6, 7)]
     for res, abl, grid, nbuf in cases:
         tp, tf, md, mr, bad = C.c_double(), C.c_double(), C.c_double(), C.c_double(), C.c_int64()
