@@ -84,6 +84,26 @@ def test_bench_world8_rehearsal():
     assert d["value"] > 0 and abs(d["value"] - 128 / 4.0 / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]
 
 
+def test_bench_under_torch_distributed_run():
+    """The driver's own command for N > 1 - `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` - with N = 2 on the box's one GPU (gloo): the launcher's RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* reach bench.py, rank 0 prints the one JSON line, nobody re-launches anything."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16",
+                        "--cpu-sample", "0", "--no-extras"], capture_output=True, text=True, timeout=900, env=_clean_env(PMP_DIST_BACKEND="gloo"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_blocks"] == 32 and d["scaling"] == "weak" and d["multi_gpu"]["rccl_ranks"] == 2
+    assert d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0
+    assert "preflight ok: 2 ranks" in r.stderr
+
+
 def test_driver_world8_rehearsal_ragged(tmp_path):
     """The driver with --gpus 8 on a geometry that does not divide: 9 sub-sampled frames of 5 x 3 blocks = 27 block rows over 8 ranks
     (three ranks take 4 rows, five take 3; frames straddle ranks).  Sharded emission and --emit gather both write the bytes of one rank."""
