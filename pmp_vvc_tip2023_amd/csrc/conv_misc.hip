@@ -151,8 +151,10 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(StemArgs a)
     static_assert(RPS * K1 <= 32 && KPP * RPS == K1, "a K-step holds whole kernel rows, a plane whole K-steps");
     constexpr int RS = PS + 16;                          // row stride of the planes in LDS
     constexpr int SEGS = OUT / 16, RB = 8, NBATCH = SEGS * (OUT / RB);
-    __shared__ _Float16 h0[CIN * PS * RS + 16];
-    __shared__ _Float16 h1[MSBD ? PS * RS + 16 : 8];     // low term of the logit plane
+    constexpr int NPIX = CIN - (MSBD ? 1 : 0);           // pixel planes (one fp16 term: exact)
+    __shared__ _Float16 h0[NPIX * PS * RS + 16];
+    __shared__ unsigned hq[MSBD ? PS * RS + 16 : 4];     // the logit plane: both fp16 terms of a value in one word (low | high << 16), so that
+                                                         // ONE 4-byte LDS read per K slot fetches what two 2-byte gathers did
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, xl = lane & 15, g = lane >> 4;
 
     const uint8_t *by = a.by + (size_t)n * 68 * 68;
@@ -180,7 +182,9 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(StemArgs a)
             _Float16 q0, q1;
             sat_report(a.sat, fabsf(qv));   // checked where it is stored, no register carried through the kernel
             split2(qv, q0, q1);
-            h0[(CIN - 1) * PS * RS + i] = q0; h1[i] = q1;
+            unsigned short b0, b1;
+            __builtin_memcpy(&b0, &q0, 2); __builtin_memcpy(&b1, &q1, 2);
+            hq[i] = (unsigned)b0 | ((unsigned)b1 << 16);
         }
     }
     __syncthreads();
@@ -199,6 +203,19 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(StemArgs a)
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = p[eo[j]];
         return v;
+    };
+    auto gather2 = [&](const unsigned *p, f16x8 &x0v, f16x8 &x1v) __attribute__((always_inline)) {
+        unsigned v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = p[eo[j]];
+        u32x4 lo, hi;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            lo[k] = __builtin_amdgcn_perm(v[2 * k + 1], v[2 * k], 0x05040100u);     // the low halves of two words
+            hi[k] = __builtin_amdgcn_perm(v[2 * k + 1], v[2 * k], 0x07060302u);     // the high halves
+        }
+        __builtin_memcpy(&x0v, &lo, 16);
+        __builtin_memcpy(&x1v, &hi, 16);
     };
     for (int b = wave; b < NBATCH; b += 4) {
         const int seg = b % SEGS, y0 = (b / SEGS) * RB, x0 = seg * 16;
@@ -221,13 +238,13 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(StemArgs a)
             constexpr int dummy = 0; (void)dummy;
             const int plane = ks / KPP, s = ks % KPP, r0 = s * RPS;
             const bool isq = MSBD && plane == CIN - 1;
-            const _Float16 *base = h0 + (plane * PS + y0) * RS + x0 + xl;
-            const _Float16 *base1 = h1 + y0 * RS + x0 + xl;
+            const _Float16 *base = h0 + ((isq ? 0 : plane) * PS + y0) * RS + x0 + xl;
+            const unsigned *baseq = hq + y0 * RS + x0 + xl;
             if (s == 0) {      // a new plane: the whole window
 #pragma unroll
                 for (int m = 0; m < RB; ++m) {
-                    win[m] = gather(base + m * RS);
-                    if (isq) win1[m] = gather(base1 + m * RS);
+                    if (isq) gather2(baseq + m * RS, win[m], win1[m]);
+                    else win[m] = gather(base + m * RS);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -253,8 +270,8 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(StemArgs a)
                 }
                 if (s + 1 < KPP && m < RPS) {   // slide the window: input row RB + r0 + m takes the slot this row just left
                     const int p = RB + r0 + m;
-                    win[p & (RB - 1)] = gather(base + p * RS);
-                    if (isq) win1[p & (RB - 1)] = gather(base1 + p * RS);
+                    if (isq) gather2(baseq + p * RS, win[p & (RB - 1)], win1[p & (RB - 1)]);
+                    else win[p & (RB - 1)] = gather(base + p * RS);
                 }
             }
         }
