@@ -134,9 +134,18 @@ def measure_extras(eng, args, dev, n, y, u, v, step):
         for qp in (22, 27, 32, 37):
             eng.load("Luma", qp)
             per_qp[str(qp)] = round(n / 4.0 / timed(lambda: step("Luma", qp), 3), 2)
+        eng.load("Luma", 22)
+        eng.set_overlap(True)       # pmp_set_overlap: two chunks of the step in flight on two streams (never inside the timed region: two
+        ov_luma = timed(lambda: step("Luma", 22), 5)       # launches share the device then and per-launch durations lose their meaning)
         eng.load("Chroma", 22)
+        ov_chroma = timed(lambda: step("Chroma", 22), 5)
+        eng.set_overlap(False)
         chroma_dt = timed(lambda: step("Chroma", 22), 3)
         out["extra"] = {"luma_ctu_per_s_by_qp": per_qp, "chroma_qp22_ctu_per_s": round(n / 4.0 / chroma_dt, 2),
+                        "overlap_mode": {"luma_qp22_ctu_per_s": round(n / 4.0 / ov_luma, 2), "luma_ms_per_step": round(ov_luma * 1e3, 3),
+                                         "chroma_qp22_ctu_per_s": round(n / 4.0 / ov_chroma, 2), "chroma_ms_per_step": round(ov_chroma * 1e3, 3),
+                                         "note": "opt-in pmp_set_overlap(ctx, 1) / PMP_OVERLAP=1: the step as two 2048-block chunks on two streams; "
+                                                 "bit-identical records; not used for `value`"},
                         "note": "device-resident step, 3 steps each after 1 warm-up; same blocks; chroma counts the 64x64-luma-area "
                                 "block (34x34 chroma inputs) as the unit, as the luma figure does"}
 

@@ -86,6 +86,15 @@ int pmp_synchronize(pmp_ctx *ctx);
 int pmp_set_chunk(pmp_ctx *ctx, int blocks);
 int64_t pmp_get_workspace_bytes(const pmp_ctx *ctx);
 
+/* Overlap mode (off by default; PMP_OVERLAP=1 in the environment turns it on at pmp_create).  A call of at least 1024 blocks is cut into
+ * (at least) two chunks; even chunks run on the context's stream and workspace, odd ones on a second, internal stream with a second
+ * workspace, forked from and joined to the context's stream by events - one chunk's small launches (stems, 16x16 tails, HBM-bound 32x32
+ * layers) then run beside the other's 64x64 convolutions.  Blocks are independent, so results do not depend on how a call is cut (bit-
+ * identical records; tests/test_gpu_parity.py).  Measured -0.2 ... -1.2 % (luma) / -0.7 ... -1.7 % (chroma) on the 4096-block step.  Two launches share
+ * the device then, so the per-launch durations of pmp_ktime_* (and of a profiler) no longer describe a kernel running alone: bench.py
+ * keeps the mode off for its timed region and reports its effect beside it. */
+int pmp_set_overlap(pmp_ctx *ctx, int on);
+
 /* Convolution datapath.  All three are fp32-accurate (EXPERIMENTS.md, precision study); results differ in the last bits only.
  *   PMP_PRECISION_F32    v_mfma_f32_16x16x4_f32, exact fp32 fmaf chain
  *   PMP_PRECISION_BF16X6 every fp32 operand carried as 3 bf16 terms, 6 bf16 MFMA products, fp32 accumulate

@@ -35,6 +35,7 @@ SIGNATURES = {
     "pmp_set_stream": (_I, [_VP, _VP]),
     "pmp_synchronize": (_I, [_VP]),
     "pmp_set_chunk": (_I, [_VP, _I]),
+    "pmp_set_overlap": (_I, [_VP, _I]),
     "pmp_get_workspace_bytes": (_I64, [_VP]),
     "pmp_set_precision": (_I, [_VP, _I]),
     "pmp_get_precision": (_I, [_VP]),

@@ -141,17 +141,42 @@ static int infer_passes(pmp_ctx *c, bool luma, NetWeights &wq, NetWeights &wb, c
     int rc0;     // weights are packed per datapath, on first use (the load packed the datapath that was current then)
     if ((rc0 = ensure_datapath(c, wq, c->precision)) != PMP_OK || (rc0 = ensure_datapath(c, wb, c->precision)) != PMP_OK) return rc0;
     if ((rc0 = abl_prepare_pass(c, wq, wb)) != PMP_OK) return rc0;
-    for (int64_t o = 0; o < n; o += c->chunk) {
-        const int m = (int)((n - o) < c->chunk ? (n - o) : c->chunk);
+    // Overlap mode: a call of at least 1024 blocks runs as (at least) two chunks, even ones on the context's stream and workspace, odd
+    // ones on a second stream with a second workspace, so that one chunk's small launches (stems, 16x16 tails, HBM-bound 32x32 layers)
+    // run beside the other's 64x64 convolutions.  Blocks are independent: the results do not depend on how a call is cut.
+    const bool overlap = c->overlap && n >= 1024;
+    int64_t chunk = c->chunk;
+    if (overlap && (n + 1) / 2 < chunk) chunk = (n + 1) / 2;
+    hipStream_t main_stream = c->stream;
+    if (overlap) {
+        hipError_t e = hipSuccess;
+        if (!c->stream2) e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+        hipEvent_t ev = get_event(c);
+        if (e == hipSuccess) e = hipEventRecord(ev, main_stream);            // fork: the second stream starts behind everything enqueued so far
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->stream2, ev, 0);
+        c->event_pool.push_back(ev);
+        if (e != hipSuccess) return hip_fail(c, e, "overlap: fork");
+    }
+    int rc = PMP_OK, k = 0;
+    for (int64_t o = 0; o < n && rc == PMP_OK; o += chunk, ++k) {
+        const int m = (int)((n - o) < chunk ? (n - o) : chunk);
         const uint8_t *y = by + o * 68 * 68;
         const uint8_t *u = bu ? bu + o * 34 * 34 : nullptr, *v = bv ? bv + o * 34 * 34 : nullptr;
         float *q = qt + o * 64;
-        int rc = run_graph(c, [&] { return forward_q(c, luma, wq, y, u, v, m, q); });
-        if (rc != PMP_OK) return rc;
-        rc = run_graph(c, [&] { return forward_msbd(c, luma, wb, y, u, v, q, m, bt + o * 768, dire + o * 768); });
-        if (rc != PMP_OK) return rc;
+        const bool side = overlap && (k & 1);
+        if (side) { c->stream = c->stream2; std::swap(c->ws, c->ws2); }
+        rc = run_graph(c, [&] { return forward_q(c, luma, wq, y, u, v, m, q); });
+        if (rc == PMP_OK) rc = run_graph(c, [&] { return forward_msbd(c, luma, wb, y, u, v, q, m, bt + o * 768, dire + o * 768); });
+        if (side) { c->stream = main_stream; std::swap(c->ws, c->ws2); }
     }
-    return PMP_OK;
+    if (overlap) {
+        hipEvent_t ev = get_event(c);
+        hipError_t e = hipEventRecord(ev, c->stream2);                       // join: the caller's stream continues behind both
+        if (e == hipSuccess) e = hipStreamWaitEvent(main_stream, ev, 0);
+        c->event_pool.push_back(ev);
+        if (e != hipSuccess && rc == PMP_OK) rc = hip_fail(c, e, "overlap: join");
+    }
+    return rc;
 }
 
 // ---- f16x3 range guard (include/pmp.h) ----------------------------------------------------------------------------------
@@ -368,6 +393,7 @@ int pmp_create(int device_id, pmp_ctx **out)
     c->device = device_id;
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return hip_fail(nullptr, e, "hipStreamCreate"); }
     c->stream = c->own_stream;
+    if (const char *ov = std::getenv("PMP_OVERLAP")) c->overlap = ov[0] == '1' && !ov[1];
     if ((e = hipMalloc((void **)&c->d_sat, 256)) != hipSuccess || (e = hipMemset(c->d_sat, 0, 256)) != hipSuccess) {
         if (c->d_sat) hipFree(c->d_sat);
         hipStreamDestroy(c->own_stream);
@@ -389,16 +415,18 @@ int pmp_destroy(pmp_ctx *c)
     if (!c) return PMP_OK;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    if (c->stream2) hipStreamSynchronize(c->stream2);
     drop_pending(c);
     ktime_drain(c);
     for (auto &kv : c->nets) free_net_weights(kv.second);
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
     park_workspace(c->device, c->ws);
-    DevBuf *bufs[] = {&c->ws, &c->d_in[0], &c->d_in[1], &c->d_in[2], &c->d_logit[0], &c->d_logit[1], &c->d_logit[2],
+    DevBuf *bufs[] = {&c->ws, &c->ws2, &c->d_in[0], &c->d_in[1], &c->d_in[2], &c->d_logit[0], &c->d_logit[1], &c->d_logit[2],
                       &c->d_out[0], &c->d_out[1], &c->d_out[2], &c->d_out[3], &c->d_frames[0], &c->d_frames[1], &c->d_frames[2]};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     if (c->d_sat) hipFree(c->d_sat);
     if (c->h_sat) hipHostFree(c->h_sat);
+    if (c->stream2) hipStreamDestroy(c->stream2);
     hipStreamDestroy(c->own_stream);
     delete c;
     return PMP_OK;
@@ -421,6 +449,13 @@ int pmp_set_stream(pmp_ctx *c, void *hip_stream)
 }
 
 int pmp_synchronize(pmp_ctx *c) { CHECK_CTX(c); return settle(c); }
+
+int pmp_set_overlap(pmp_ctx *c, int on)
+{
+    if (!c) return PMP_E_INVALID;
+    c->overlap = on ? 1 : 0;
+    return PMP_OK;
+}
 
 int pmp_set_chunk(pmp_ctx *c, int blocks)
 {

@@ -129,6 +129,9 @@ struct pmp_ctx {
     std::map<int, pmp::NetWeights> nets;  // key = net_id * 100 + qp
     pmp::Arena arena;
     pmp::DevBuf ws;                        // activation workspace (its own, or a larger one parked by a destroyed context)
+    pmp::DevBuf ws2;                       // second workspace: the passes of odd chunks on `stream2` (overlap mode)
+    hipStream_t stream2 = nullptr;         // created on first use
+    int overlap = 0;                       // two chunks in flight on two streams (PMP_OVERLAP=1 in the environment at pmp_create)
     size_t ws_need = 0;                    // what the largest pass so far needed of it (pmp_get_workspace_bytes)
     pmp::DevBuf d_in[3], d_logit[3], d_out[4], d_frames[3];  // staging for the host-pointer entry points
     // kernel-class timing

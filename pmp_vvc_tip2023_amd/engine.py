@@ -65,6 +65,10 @@ class Engine:
     def set_chunk(self, blocks):
         self._ck(self.lib.pmp_set_chunk(self.h, int(blocks)))
 
+    def set_overlap(self, on):
+        """Two chunks of a large call in flight on two streams (include/pmp.h: pmp_set_overlap)."""
+        self._ck(self.lib.pmp_set_overlap(self.h, 1 if on else 0))
+
     def workspace_bytes(self):
         return int(self.lib.pmp_get_workspace_bytes(self.h))
 

@@ -205,6 +205,56 @@ def test_parking_can_be_turned_off(g1, monkeypatch):
     assert lib.pmp_trim() == 0
 
 
+def test_overlap_mode_is_bit_identical(g1):
+    """pmp_set_overlap: a call of >= 1024 blocks runs as two chunks on two streams with two workspaces.  Logits and flags equal the
+    default mode's bit for bit (both components, a ragged size, records through the device entry point), smaller calls are not cut, and
+    a range-guard re-run behind an overlapped call still repairs it."""
+    import torch
+    from pmp_vvc_tip2023_amd import engine, synth, weights as W
+    n = 1500
+    y, u, v = synth.recipe_r_blocks(n, 21)
+    e = engine.Engine(0, allow_synthetic_mtt=True)
+    try:
+        for comp in ("Luma", "Chroma"):
+            ref = e.infer_postprocess(comp, 22, y, u, v, want_logits=True)
+            need = e.workspace_bytes()
+            e.set_overlap(True)
+            got = e.infer_postprocess(comp, 22, y, u, v, want_logits=True)
+            assert e.workspace_bytes() == need                    # what a pass needs: the larger of the chunks, as before (<= the uncut call's)
+            small = e.infer_postprocess(comp, 22, y[:700], u[:700], v[:700], want_logits=True)     # below the threshold: one chunk
+            e.set_overlap(False)
+            for a, b in zip(ref, got):
+                assert np.array_equal(a, b), comp
+            for a, b in zip(ref, small):
+                assert np.array_equal(a[:700], b), comp
+        # records through the device-pointer entry point, twice in flight
+        dev = torch.device("cuda:0")
+        d_y = torch.from_numpy(y).to(dev)
+        recs = []
+        for ov in (False, True):
+            e.set_overlap(ov)
+            r = [torch.empty((n, 1344), dtype=torch.uint8, device=dev) for _ in range(2)]
+            for k in range(2):
+                e.infer_postprocess_records_device("Luma", 22, d_y.data_ptr(), None, None, n, r[k].data_ptr())
+            e.synchronize()
+            recs.append([x.cpu().numpy() for x in r])
+        assert all(np.array_equal(recs[0][0], x) for x in recs[0][1:] + recs[1])
+        # the range guard under overlap: stress weights saturate f16x3 in every chunk; the call is re-run on fp32 MFMA as a whole
+        w = _range_stress_weights()
+        yy = np.ascontiguousarray(np.concatenate([g1["block_y"]] * 70)[:1100])
+        e.load("Luma", 22)
+        e.load_pretrain_model("Luma_MSBD", 22, w)
+        e.set_overlap(False)
+        q0, b0, d0 = e.inference_pre_QBD("Luma", 22, yy)
+        r0 = e.saturation_reruns()
+        e.set_overlap(True)
+        q1, b1, d1 = e.inference_pre_QBD("Luma", 22, yy)
+        assert e.saturation_reruns() == r0 + 1 and r0 >= 1
+        assert np.array_equal(q0, q1) and np.array_equal(b0, b1) and np.array_equal(d0, d1)
+    finally:
+        e.close()
+
+
 def test_default_chunk_boundary(eng):
     """More blocks than one library pass (default chunk 4096): the ragged second pass gives what a call on those blocks alone gives."""
     from pmp_vvc_tip2023_amd import synth
