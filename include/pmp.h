@@ -82,7 +82,8 @@ int pmp_synchronize(pmp_ctx *ctx);
  * 4096.  The activation workspace is sized for the blocks a pass actually runs, min(n, chunk), and tensors share memory once
  * their last consumer is enqueued: 2.5 MB per luma block on the default datapath (10 GB for a full 4096-block pass, 10 MB
  * for a 4-block call; bf16x6 3.75 MB, chroma 1.1 MB per block); it only grows, to what the largest pass so far needed.
- * pmp_get_workspace_bytes reports that need (the buffer behind it may be a larger one taken over from a destroyed context, see pmp_trim). */
+ * pmp_get_workspace_bytes reports that need (the buffer behind it may be a larger one taken over from a destroyed context, see pmp_trim),
+ * plus the second workspace overlap mode holds while it is on (sized for its half-call chunks; freed by pmp_set_overlap(ctx, 0)). */
 int pmp_set_chunk(pmp_ctx *ctx, int blocks);
 int64_t pmp_get_workspace_bytes(const pmp_ctx *ctx);
 
@@ -249,7 +250,7 @@ int pmp_debug_set_winograd(pmp_ctx *ctx, int on);
 /* ---- test / A-B hook (f16x3 datapath, per context): on = 1 (default) runs the 16x16-resolution tails of the nets - trunk_B1/B2 +
  *      heads + attention 1 of the MTT nets, resblock_q3 .. conv_q2 of the QT nets - as ONE launch per net with the activations
  *      resident in LDS (chain16.hip); on = 0 runs them launch per layer, as the other two datapaths always do.  Results are
- *      BIT-IDENTICAL either way (tests/test_gpu_parity.py::test_fused_16x16_tails_are_bit_identical); only the launch count (84 -> 54
+ *      BIT-IDENTICAL either way (tests/test_gpu_parity.py::test_fused_16x16_tails_are_bit_identical); only the launch count (68 -> 41
  *      per luma pass) and the time differ.  Settles the calls in flight first. ---- */
 int pmp_debug_set_fusion(pmp_ctx *ctx, int on);
 

@@ -169,7 +169,7 @@ std::vector<unsigned short> pack_h2(const float *w, int cout, int cin, int kh, i
 // plane; a K-step of 32 slots holds RPS whole kernel rows of one plane (k1 = 9: 3 rows = 27 slots; k1 = 5: 5 rows = 25 slots), slot
 // k = (dy - r0) * k1 + dx, the rest zero.
 // Stream: [K-step][3 splits][2 cout groups][64 lanes][8] fp16 terms of 2^scale_exp * w.  THREE terms (33 significand bits: the fp32 weight
-// exactly), not the two of the other layers: the pixels are exact in fp16, so with exact weights every product of the first layer is exact
+// to 2^-37 of the tensor's maximum - exactly, unless it lies more than 2^13 below that maximum), not the two of the other layers: the pixels are exact in fp16, so with exact weights every product of the first layer is exact
 // - and this is the layer whose weight error the Luma_Q net amplifies most (raw 0..255 inputs, outputs in the thousands, logits of order
 // 1).  A weight's 2^-23 representation error is the same for every pixel it meets, so it adds up coherently where rounding noise
 // averages out: on the worst block of the 15 840-block campaign two-term stem weights alone cost 5e-4 of the 1e-3 tolerance, three

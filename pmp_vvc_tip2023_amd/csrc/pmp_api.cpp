@@ -341,6 +341,11 @@ static int settle(pmp_ctx *c)
     return rc != PMP_OK ? rc : sync(c);
 }
 
+// Host-pointer entry points stage through the context's own buffers (d_in, d_logit, d_out) and return final results.  A *_device call
+// that is still in flight may re-run into those very buffers once its range flag is looked at (and a replayed post-processing call may
+// read them), so everything pending is made final BEFORE the host call stages anything: afterwards the queue holds this call only.
+static int settle_before_host_call(pmp_ctx *c) { return c->pending.empty() ? PMP_OK : settle(c); }
+
 static int h2d(pmp_ctx *c, DevBuf &b, const void *src, size_t bytes)
 {
     int rc = ensure(c, b, bytes ? bytes : 1);
@@ -385,7 +390,7 @@ int pmp_create(int device_id, pmp_ctx **out)
     if ((e = hipSetDevice(device_id)) != hipSuccess) return hip_fail(nullptr, e, "hipSetDevice");
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return hip_fail(nullptr, e, "hipGetDeviceProperties");
-    abl_on_create();     // no-op: the product library reads no environment variable
+    abl_on_create();     // no-op in the product library (its own environment knobs: PMP_OVERLAP here, PMP_PARK_WORKSPACE at pmp_destroy)
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
         return set_err(nullptr, PMP_E_NODEVICE, std::string("pmp_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName);
     pmp_ctx *c = new (std::nothrow) pmp_ctx();
@@ -452,8 +457,10 @@ int pmp_synchronize(pmp_ctx *c) { CHECK_CTX(c); return settle(c); }
 
 int pmp_set_overlap(pmp_ctx *c, int on)
 {
-    if (!c) return PMP_E_INVALID;
+    CHECK_CTX(c);
+    if (!c->pending.empty()) { const int rc = settle(c); if (rc != PMP_OK) return rc; }   // calls in flight keep the cut they were made with
     c->overlap = on ? 1 : 0;
+    if (!c->overlap && c->ws2.p) { hipFree(c->ws2.p); c->ws2 = DevBuf(); }                // the second workspace exists only while the mode is on
     return PMP_OK;
 }
 
@@ -465,7 +472,7 @@ int pmp_set_chunk(pmp_ctx *c, int blocks)
     return PMP_OK;
 }
 
-int64_t pmp_get_workspace_bytes(const pmp_ctx *c) { return c ? (int64_t)c->ws_need : PMP_E_INVALID; }
+int64_t pmp_get_workspace_bytes(const pmp_ctx *c) { return c ? (int64_t)(c->ws_need + c->ws2.cap) : PMP_E_INVALID; }   // + the second workspace while overlap mode holds one
 
 int pmp_set_precision(pmp_ctx *c, int mode)
 {
@@ -627,11 +634,12 @@ int pmp_infer(pmp_ctx *c, int comp, int qp, const uint8_t *by, const uint8_t *bu
         return set_err(c, PMP_E_INVALID, "pmp_infer: null buffer or negative count");
     if (n == 0) return PMP_OK;
     int rc;
+    if ((rc = settle_before_host_call(c))) return rc;
     if ((rc = stage_blocks(c, comp, by, bu, bv, n))) return rc;
     if ((rc = ensure_logits(c, n))) return rc;
     float *dq = (float *)c->d_logit[0].p, *db = (float *)c->d_logit[1].p, *dd = (float *)c->d_logit[2].p;
     if ((rc = infer_device_impl(c, comp, qp, (const uint8_t *)c->d_in[0].p, (const uint8_t *)c->d_in[1].p,
-                                (const uint8_t *)c->d_in[2].p, n, dq, db, dd)))
+                                (const uint8_t *)c->d_in[2].p, n, dq, db, dd, true)))
         return rc;
     if ((rc = resolve_pending(c, true))) return rc;      // range guard: a re-run is enqueued before the copies below
     if ((rc = d2h(c, qt, dq, (size_t)n * 64 * 4)) || (rc = d2h(c, bt, db, (size_t)n * 768 * 4)) ||
@@ -667,6 +675,7 @@ int pmp_postprocess(pmp_ctx *c, int comp, const float *qt, const float *bt, cons
         return set_err(c, PMP_E_INVALID, "pmp_postprocess: null buffer or negative count");
     if (n == 0) return PMP_OK;
     int rc;
+    if ((rc = settle_before_host_call(c))) return rc;
     if ((rc = ensure_logits(c, n))) return rc;
     if ((rc = h2d(c, c->d_logit[0], qt, (size_t)n * 64 * 4)) || (rc = h2d(c, c->d_logit[1], bt, (size_t)n * 768 * 4)) ||
         (rc = h2d(c, c->d_logit[2], dire, (size_t)n * 768 * 4)) || (rc = alloc_out(c, n)))
@@ -686,11 +695,12 @@ int pmp_infer_postprocess(pmp_ctx *c, int comp, int qp, const uint8_t *by, const
         return set_err(c, PMP_E_INVALID, "pmp_infer_postprocess: null buffer or negative count");
     if (n == 0) return PMP_OK;
     int rc;
+    if ((rc = settle_before_host_call(c))) return rc;
     if ((rc = stage_blocks(c, comp, by, bu, bv, n)) || (rc = alloc_out(c, n))) return rc;
     if ((rc = ensure_logits(c, n))) return rc;
     float *dq = (float *)c->d_logit[0].p, *db = (float *)c->d_logit[1].p, *dd = (float *)c->d_logit[2].p;
     if ((rc = infer_device_impl(c, comp, qp, (const uint8_t *)c->d_in[0].p, (const uint8_t *)c->d_in[1].p,
-                                (const uint8_t *)c->d_in[2].p, n, dq, db, dd)))
+                                (const uint8_t *)c->d_in[2].p, n, dq, db, dd, true)))
         return rc;
     if ((rc = post_device_impl(c, comp, dq, db, dd, n, (uint8_t *)c->d_out[0].p, (uint8_t *)c->d_out[1].p,
                                (uint8_t *)c->d_out[2].p, (int8_t *)c->d_out[3].p)))

@@ -50,6 +50,13 @@ def unpack_records(rec):
             rec[:, 512:576].reshape(n, 8, 8).copy(), rec[:, 576:].copy().view(np.int8).reshape(n, 3, 16, 16))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 INIT_TIMEOUT_S = 180           # rendezvous + preflight: a rank that never arrives becomes an error, not a hang
 COLLECTIVE_TIMEOUT_S = 1800    # steady state: a rank slowed by disk, a long first touch or a range-guard re-run is late, not missing
 
@@ -66,7 +73,11 @@ def init_process_group(device=None, timeout_s=None, force=False):
         import torch.distributed as dist
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29517")
+            if "MASTER_PORT" not in os.environ:
+                if world > 1:
+                    raise RuntimeError("init_process_group: WORLD_SIZE=%d without MASTER_PORT - start the ranks with torch.distributed.run "
+                                       "or parallel.spawn_ranks" % world)
+                os.environ["MASTER_PORT"] = str(_free_port())     # a forced one-rank group: any free port, so two such jobs never collide
             backend = os.environ.get("PMP_DIST_BACKEND") or ("nccl" if (device is not None and torch.cuda.is_available()) else "gloo")
             kw = {"device_id": device} if backend == "nccl" else {}
             t = float(os.environ.get("PMP_DIST_TIMEOUT_S", timeout_s or INIT_TIMEOUT_S))
@@ -85,8 +96,12 @@ def relax_timeout():
     t = float(os.environ.get("PMP_DIST_COLLECTIVE_TIMEOUT_S", COLLECTIVE_TIMEOUT_S))
     try:
         dist.distributed_c10d._set_pg_timeout(datetime.timedelta(seconds=t), None)     # RCCL and gloo process groups both honour it
-    except Exception:                                          # noqa: BLE001 - a torch without it: the init timeout stays in force
-        return float(os.environ.get("PMP_DIST_TIMEOUT_S", INIT_TIMEOUT_S))
+    except Exception as e:                                     # noqa: BLE001 - a torch without it: the init timeout stays in force
+        t0 = float(os.environ.get("PMP_DIST_TIMEOUT_S", INIT_TIMEOUT_S))
+        import sys
+        print("pmp parallel: this torch cannot raise the process group's timeout (%s: %s); collectives keep the rendezvous bound of %g s - "
+              "set PMP_DIST_TIMEOUT_S to what the slowest pass needs" % (type(e).__name__, e, t0), file=sys.stderr)
+        return t0
     return t
 
 
@@ -130,14 +145,11 @@ def spawn_ranks(cmd, n, env_extra=None, capture_rank0=False, poll_s=0.05):
     returned.  Rank 0 inherits this process's stdout (the reference driver prints its progress there), the other ranks' stdout goes
     to stderr; capture_rank0: rank 0's stdout is collected instead (on a thread, so a full pipe never blocks it) and returned.
     Returns (exit code, rank-0 stdout bytes or None)."""
-    import socket
     import subprocess
     import sys
     import threading
     import time
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    port = _free_port()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
     env.update(env_extra or {})

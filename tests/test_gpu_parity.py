@@ -220,9 +220,10 @@ def test_overlap_mode_is_bit_identical(g1):
             need = e.workspace_bytes()
             e.set_overlap(True)
             got = e.infer_postprocess(comp, 22, y, u, v, want_logits=True)
-            assert e.workspace_bytes() == need                    # what a pass needs: the larger of the chunks, as before (<= the uncut call's)
+            assert need < e.workspace_bytes() <= 2 * need         # + the second workspace, sized for a half-call chunk, while the mode is on
             small = e.infer_postprocess(comp, 22, y[:700], u[:700], v[:700], want_logits=True)     # below the threshold: one chunk
             e.set_overlap(False)
+            assert e.workspace_bytes() == need                    # turning the mode off frees the second workspace
             for a, b in zip(ref, got):
                 assert np.array_equal(a, b), comp
             for a, b in zip(ref, small):
@@ -463,6 +464,30 @@ def test_device_calls_do_not_stall_the_host_and_the_guard_still_repairs(g1, orac
                 assert torch.equal(a4, w4)                         # the record fields are the four arrays of (ii)
             assert torch.equal(ra, want_a), "records of the saturating call A differ after the deferred re-run (%d blocks in B)" % nb
             assert torch.equal(rb, want_b), "records of the ordinary call B were overwritten by A's re-run (%d blocks in B)" % nb
+        # ---- (v) a saturating records call still pending when a HOST-pointer call arrives: the host call stages through the context's
+        #      own logit buffers, which A's re-run writes - A must be settled first, and the host call must return ITS OWN results
+        yh, _, _ = synth.recipe_r_blocks(9, 502)
+        ref_h = e2.inference_pre_QBD("Luma", 27, yh)              # nothing pending: the reference
+        ref_p = e2.post_process(*ref_h, "Luma")
+        for host_call in ("infer", "postprocess", "infer_postprocess"):
+            e2.clear_saturation()
+            ra = torch.zeros((6, 1344), dtype=torch.uint8, device=dev)
+            e2.infer_postprocess_records_device("Luma", 22, d_yb.data_ptr(), None, None, 6, ra.data_ptr())
+            if host_call == "infer":
+                got = e2.inference_pre_QBD("Luma", 27, yh)
+                for a5, b5 in zip(got, ref_h):
+                    assert np.array_equal(a5, b5), "pmp_infer behind a pending saturated call returned foreign logits"
+            elif host_call == "postprocess":
+                got = e2.post_process(*ref_h, "Luma")
+                for a5, b5 in zip(got, ref_p):
+                    assert np.array_equal(a5, b5), "pmp_postprocess behind a pending saturated call read foreign logits"
+            else:
+                got = e2.infer_postprocess("Luma", 27, yh, want_logits=True)
+                for a5, b5 in zip(got, tuple(ref_p) + tuple(ref_h)):
+                    assert np.array_equal(a5, b5), "pmp_infer_postprocess behind a pending saturated call returned foreign results"
+            e2.synchronize()
+            assert e2.saturation_reruns() == 1
+            assert torch.equal(ra, want_a), "records of the saturating call A differ after a host call settled it (%s)" % host_call
         # ---- the error policy reports at the call that looks at the flag
         from pmp_vvc_tip2023_amd import _lib
         e2.set_saturation_policy("error")
