@@ -1,0 +1,107 @@
+"""GPU parity on TRAINED-LIKE MTT weights (synth.trained_like_msbd_weights: tensors bootstrapped from the real QT-net tensors, trunk
+activations at the QT nets' 1e3 range, gated products to 1e4; the reference's *_BD_*.pkl are absent from the mount).
+Goldens: tests/golden/g2b_msbd_trained_like.npz, written by tools/gen_golden.py from the REFERENCE's MTT modules
+(Model_QBD.py:100-155, :198-253) holding exactly these tensors.  Tolerance: north_star's 1e-3 on the logits."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+@pytest.fixture(scope="module", params=["f16x3", "bf16x6", "fp32"])
+def eng(request):
+    from pmp_vvc_tip2023_amd import engine
+    e = engine.Engine(0, allow_synthetic_mtt=True)
+    e.set_precision(request.param)
+    yield e
+    e.close()
+
+
+def _load_tl(e, comp, qp, **gains):
+    from pmp_vvc_tip2023_amd import synth
+    w = synth.trained_like_msbd_weights(comp, qp, **gains)
+    e.load(comp, qp, msbd_weights=w)                              # the real QT net from weights/, the MTT net replaced
+    return w
+
+
+def _golden_err(bt, dire, g2b, comp, qp):
+    errs = []
+    for k in range(3):
+        ref = g2b["out%d_%s_%d" % (k, comp, qp)]                  # [16,2,16,16]: ch0 depth, ch1 direction
+        errs += [np.abs(bt[:, k] - ref[:, 0]).max(), np.abs(dire[:, k] - ref[:, 1]).max()]
+    return float(max(errs))
+
+
+@pytest.mark.parametrize("comp", ["Luma", "Chroma"])
+@pytest.mark.parametrize("qp", [22, 27, 32, 37])
+def test_trained_like_logits_vs_reference_golden(eng, comp, qp):
+    """All eight nets, all three datapaths, against the reference modules' outputs; the default datapath must get there WITHOUT the
+    range guard's fp32 re-run (trunks at 1e3, gate products to 1e4: inside the fp16 range)."""
+    g1, g2b = golden("g1_qt.npz"), golden("g2b_msbd_trained_like.npz")
+    _load_tl(eng, comp, qp)
+    eng.clear_saturation()
+    qt, bt, dire = eng.inference_pre_QBD(comp, qp, g1["block_y"], g1["block_u"], g1["block_v"])
+    assert np.abs(qt - g1["qt_%s_%d" % (comp, qp)]).max() < TOL
+    err = _golden_err(bt, dire, g2b, comp, qp)
+    assert err < TOL, "%s QP%d trained-like MTT logits off by %g" % (comp, qp, err)
+    assert eng.saturation_reruns() == 0 and not eng.saturated()
+
+
+_ORACLE = {}
+
+
+def _oracle(comp, qp, n):
+    from oracle import nets_torch as O
+    from pmp_vvc_tip2023_amd import synth, weights as W
+    key = (comp, qp, n)
+    if key not in _ORACLE:
+        import os
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        y, u, v = synth.recipe_r_blocks(n, 7000 + qp + (3 if comp == "Chroma" else 0))
+        y[0] = 0; u[0] = 0; v[0] = 0
+        y[1] = 255; u[1] = 255; v[1] = 255
+        rng = np.random.default_rng(qp)
+        y[2] = rng.integers(0, 256, y[2].shape); u[2] = rng.integers(0, 256, u[2].shape); v[2] = rng.integers(0, 256, v[2].shape)   # white noise
+        y[3] = np.where((np.arange(68)[:, None] // 2 + np.arange(68)[None, :] // 2) % 2, 255, 0)                                   # 2-px checkerboard
+        luma = comp == "Luma"
+        wq, _ = W.load_net_weights(comp + "_Q", qp)
+        wbd = synth.trained_like_msbd_weights(comp, qp)
+        x = O.luma_input(y) if luma else O.chroma_input(y, u, v)
+        _ORACLE[key] = (y, u, v) + tuple(O.infer_qbd(wq, wbd, x, luma, batch=64))
+    return _ORACLE[key]
+
+
+@pytest.mark.parametrize("comp,qp", [("Luma", 22), ("Luma", 37), ("Chroma", 27), ("Chroma", 37)])
+def test_trained_like_512_fresh_blocks_vs_oracle(eng, comp, qp):
+    """512 fresh blocks (flat, saturated, white-noise and checkerboard blocks included) against the torch oracle holding the same
+    tensors; the record of what the guard did rides along."""
+    y, u, v, oq, obt, odire = _oracle(comp, qp, 512)
+    _load_tl(eng, comp, qp)
+    eng.clear_saturation()
+    qt, bt, dire = eng.inference_pre_QBD(comp, qp, y, u, v)
+    err = max(np.abs(qt - oq).max(), np.abs(bt - obt).max(), np.abs(dire - odire).max())
+    print("trained-like %s QP%d %s: max |logit - oracle| = %.2e on 512 blocks, reruns %d" % (comp, qp, eng.get_precision(), err, eng.saturation_reruns()))
+    assert err < TOL, "%s QP%d off by %g" % (comp, qp, err)
+    assert eng.saturation_reruns() == 0
+
+
+@pytest.mark.parametrize("comp,qp", [("Luma", 22), ("Chroma", 27)])
+@pytest.mark.parametrize("gains", [(64.0, 1.0), (1.0, 16.0), (64.0, 16.0), (1.0, 1024.0), (4096.0, 64.0)])
+def test_trained_like_stress_gains_stay_on_the_default_datapath(eng, comp, qp, gains):
+    """trunk_gain K / gate_gain G are exact powers of two that the heads undo (synth.py): the reference's logits do not change (pinned
+    while the goldens were generated), but the trunks now run at K x 1e3 and the gated products at K x G x 1e4 - far outside fp16.
+    The default datapath must still deliver the golden logits, and must do so WITHOUT falling back to the 2.8x slower fp32 re-run:
+    the per-segment power-of-two activation scales chosen when the net is first used absorb the range (include/pmp.h)."""
+    g1, g2b = golden("g1_qt.npz"), golden("g2b_msbd_trained_like.npz")
+    K, G = gains
+    _load_tl(eng, comp, qp, trunk_gain=K, gate_gain=G)
+    eng.clear_saturation()
+    qt, bt, dire = eng.inference_pre_QBD(comp, qp, g1["block_y"], g1["block_u"], g1["block_v"])
+    err = _golden_err(bt, dire, g2b, comp, qp)
+    print("trained-like %s QP%d K=%g G=%g %s: err %.2e reruns %d" % (comp, qp, K, G, eng.get_precision(), err, eng.saturation_reruns()))
+    assert err < TOL, "%s QP%d K=%g G=%g off by %g" % (comp, qp, K, G, err)
+    assert eng.saturation_reruns() == 0, "the range guard fell back to fp32 (%d re-runs)" % eng.saturation_reruns()

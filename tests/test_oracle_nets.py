@@ -72,3 +72,30 @@ def test_synth_weights_are_deterministic_and_complete():
     # PRNG known answers (SplitMix64 reference values for seed 0)
     z = synth.splitmix64(0, 3)
     assert [int(v) for v in z] == [0xE220A8397B1DCDAF, 0x6E789E6AA1B965F4, 0x06C45D188009454F]
+
+
+@pytest.mark.parametrize("comp", ["Luma", "Chroma"])
+@pytest.mark.parametrize("qp", [22, 27, 32, 37])
+def test_msbd_net_trained_like_weights(comp, qp):
+    """G2b: the reference's MTT modules holding synth.trained_like_msbd_weights (bootstrapped from the real QT tensors; trunks at 1e3).
+    The oracle on the same tensors, the activation maxima that ride along, and the power-of-two stress variants, which must not
+    change a single bit of the logits (the heads undo the gains exactly)."""
+    g1, g2b = golden("g1_qt.npz"), golden("g2b_msbd_trained_like.npz")
+    luma = comp == "Luma"
+    x = O.luma_input(g1["block_y"]) if luma else O.chroma_input(g1["block_y"], g1["block_u"], g1["block_v"])
+    q = torch.from_numpy(g1["qt_%s_%d" % (comp, qp)])
+    wbd = synth.trained_like_msbd_weights(comp, qp)
+    assert len(wbd) == 72 and all(v.dtype == np.float32 for v in wbd.values())
+    taps = {}
+    with torch.no_grad():
+        o = O.msbd_forward(wbd, x, q, luma, taps=taps)
+        o2 = O.msbd_forward(synth.trained_like_msbd_weights(comp, qp, trunk_gain=64.0, gate_gain=16.0), x, q, luma)
+    for i in range(3):
+        assert np.abs(o[i].numpy() - g2b["out%d_%s_%d" % (i, comp, qp)]).max() < TOL
+        assert torch.equal(o[i], o2[i])
+    amax = g2b["amax_%s_%d" % (comp, qp)]                     # x3 x4 x5 att0 att1 xb1 xb3
+    got = [taps[k].abs().max().item() for k in ("x3", "x4", "x5", "x_att0", "x_att1")]
+    assert np.allclose(got, amax[:5], rtol=1e-3)
+    assert 300 < amax[1] < 3000 and 300 < amax[2] < 3000      # the trunks run where the trained QT nets run (SURVEY: 3e3 on 8-bit content)
+    with pytest.raises(ValueError):
+        synth.trained_like_msbd_weights(comp, qp, gate_gain=3.0)

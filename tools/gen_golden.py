@@ -4,6 +4,8 @@ Run in the build container only (needs /root/reference):   python tools/gen_gold
 Every output is produced by calling the reference's own functions:
   G1  Model_QBD.{Luma,Chroma}_Q_Net          real weights, 4 QPs           -> g1_qt.npz
   G2  Model_QBD.{Luma,Chroma}_MSBD_Net       synthetic weights (synth.py)  -> g2_msbd.npz
+  G2b Model_QBD.{Luma,Chroma}_MSBD_Net       TRAINED-LIKE weights (synth.trained_like_msbd_weights: bootstrapped from the real QT
+                                             tensors, trunks at 1e3, gated products to 9e3), 4 QPs -> g2b_msbd_trained_like.npz
   G3  Map2Partition.map_to_parititon         random/adversarial maps       -> g3_m2p.npz
   G4  Metrics.eli_structual_error            random logits                 -> g4_eli.npz
   G5  Map2Partition.get_sequence_partition_for_VTM (text bytes)            -> g5_seq.npz + g5_partitionmat.txt
@@ -87,6 +89,42 @@ def gen_g1_g2():
             print("G1/G2", comp, qp, "qt range %.2f..%.2f" % (q.min(), q.max()))
     np.savez_compressed(os.path.join(OUT, "g1_qt.npz"), **g1)
     np.savez_compressed(os.path.join(OUT, "g2_msbd.npz"), **g2)
+
+
+# ----------------------------------------------------------------------------------------------- G2b
+def gen_g2b():
+    """The reference's MTT modules holding the trained-like weights: all eight (component, QP) nets on the 16 G1 blocks with the G1
+    logits as q.  Also pins (i) the per-tensor activation maxima the GPU tests compare the library's own range report with, and
+    (ii) that the power-of-two stress variants (trunk_gain, gate_gain) leave the reference's logits bit-identical."""
+    g1 = dict(np.load(os.path.join(OUT, "g1_qt.npz")))
+    y, u, v = g1["block_y"], g1["block_u"], g1["block_v"]
+    out = {"meta": np.array(META + "; MSBD weights = synth.trained_like_msbd_weights(comp, qp); inputs = g1 blocks, q = g1 logits")}
+    for comp in ("Luma", "Chroma"):
+        luma = comp == "Luma"
+        x = O.luma_input(y) if luma else O.chroma_input(y, u, v)
+        for qp in (22, 27, 32, 37):
+            q = torch.from_numpy(g1["qt_%s_%d" % (comp, qp)])
+            wbd = synth.trained_like_msbd_weights(comp, qp)
+            net = R.ref_net(comp + "_MSBD", wbd)
+            taps = {}
+            with torch.no_grad():
+                o = net(x, q)
+                o_or = O.msbd_forward(wbd, x, q, luma, taps=taps)
+                net2 = R.ref_net(comp + "_MSBD", synth.trained_like_msbd_weights(comp, qp, trunk_gain=64.0, gate_gain=16.0))
+                o2 = net2(x, q)
+            for a, b in zip(o, o_or):
+                assert (a - b).abs().max().item() < 1e-4, "oracle MSBD restatement drifted (trained-like weights)"
+            for a, b in zip(o, o2):
+                assert torch.equal(a, b), "power-of-two gains changed the reference's logits"
+            for i in range(3):
+                out["out%d_%s_%d" % (i, comp, qp)] = o[i].numpy()
+            xb1 = taps["x5"] * taps["x_att0"]
+            xb3 = taps["x4"] * taps["x_att1"]
+            out["amax_%s_%d" % (comp, qp)] = np.array([taps[k].abs().max().item() for k in ("x3", "x4", "x5", "x_att0", "x_att1")] +
+                                                      [xb1.abs().max().item(), xb3.abs().max().item()], np.float32)
+            print("G2b", comp, qp, "logits %.2f..%.2f" % (min(t.min() for t in o), max(t.max() for t in o)),
+                  "max |x3 x4 x5 att0 att1 xb1 xb3| =", " ".join("%.0f" % t for t in out["amax_%s_%d" % (comp, qp)]))
+    np.savez_compressed(os.path.join(OUT, "g2b_msbd_trained_like.npz"), **out)
 
 
 # ------------------------------------------------------------------------------------------------ G3
@@ -289,8 +327,9 @@ def gen_g7():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2b", "g3", "g4", "g5", "g6", "g7"]
     if "g1" in which: gen_g1_g2()
+    if "g2b" in which: gen_g2b()
     if "g3" in which: gen_g3()
     if "g4" in which: gen_g4()
     if "g5" in which: gen_g5()
