@@ -125,6 +125,19 @@ int pmp_get_precision(const pmp_ctx *ctx);
  *   PMP_SAT_IGNORE           no snapshots, no re-runs; the caller polls
  * pmp_get_saturation settles the calls in flight and returns 1 if any inference call of this context saturated since the last
  * pmp_clear_saturation (0 otherwise, negative on error); pmp_get_saturation_reruns counts the calls that were re-run. */
+/* Activation scales of the f16x3 datapath (MTT nets).  The range guard above is a safety net; what keeps a net with large activations
+ * ON the default datapath is this: the MTT nets are bias-free behind their stems, and ReLU, max-pool and the two gate products
+ * (Model_QBD.py:143,150) are positively homogeneous, so a tensor can travel as true * 2^-e - exactly: a power of two commutes with
+ * every rounding - if its consumer knows e.  The graph has five segments (stem..trunk_M1..trunk_M2..trunk_B1 | attention 1 | x5*att0..
+ * trunk_B2 | attention 2 | x4*att1..trunk_B3) with one exponent each; the changes of scale are folded into numbers the kernels multiply
+ * by anyway (the stem's output scale and biases, the out_scale of the convolution whose epilogue applies a gate, the head weights), so
+ * they cost nothing per call.  The exponents are chosen when a (QT, MTT) pair is first used on the f16x3 datapath: one pass of both nets
+ * over 32 built-in calibration blocks (flat, checkerboards, stripes, edges, white noise, smooth random content) on the fp32 MFMA
+ * datapath records the largest |value| of every MTT tensor, and a segment whose maximum exceeds 2^12 gets the exponent that brings it
+ * there (16x headroom below 65504 for content harsher than the calibration set; the attention trunks start from logits and keep e = 0).
+ * Deterministic: same weights, same exponents, on every context and rank.  Exponents of zero - the synthetic uniform MTT weights, any
+ * net whose activations stay below 4096 - leave the arithmetic exactly as it was.  That first use synchronises the stream once.
+ * pmp_debug_activation_report (below) returns the exponents and the recorded maxima. */
 #define PMP_SAT_RERUN 0
 #define PMP_SAT_ERROR 1
 #define PMP_SAT_IGNORE 2
@@ -253,6 +266,13 @@ int pmp_debug_set_winograd(pmp_ctx *ctx, int on);
  *      BIT-IDENTICAL either way (tests/test_gpu_parity.py::test_fused_16x16_tails_are_bit_identical); only the launch count (68 -> 41
  *      per luma pass) and the time differ.  Settles the calls in flight first. ---- */
 int pmp_debug_set_fusion(pmp_ctx *ctx, int on);
+
+/* ---- test / diagnosis hook: the f16x3 activation scales of the MTT net of (comp, qp) (see "Activation scales" above) and the calibration
+ *      record behind them.  Runs the calibration now if the pair has not been used on the f16x3 datapath yet (both nets must be loaded).
+ *      exps[5]: the segment exponents; seg_amax[5]: the largest |value| seen in each segment on the calibration blocks (true scale);
+ *      buf (may be NULL): one text line per recorded tensor, "<name> <segment> <max |value|>\n", in launch order ("<block>.t" is the
+ *      intermediate of a ResidualBlock).  Returns the number of recorded tensors or a negative error. ---- */
+int pmp_debug_activation_report(pmp_ctx *ctx, int comp, int qp, int exps[5], float seg_amax[5], char *buf, int64_t cap);
 
 /* ---- test hook (host only, no GPU needed): the f16x3 weight packing of one OIHW conv tensor (conv_f16x3.hip).
  *      Writes the power-of-two exponent k of the scale S = 2^k to *scale_exp and, if out != NULL, the packed stream

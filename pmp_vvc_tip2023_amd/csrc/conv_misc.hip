@@ -527,6 +527,30 @@ __global__ __launch_bounds__(256) void multipool_concat_kernel(const float *__re
     }
 }
 
+// ---- calibration of the f16x3 activation scales (pmp_api.cpp: calibrate_mtt): largest |value| of an fp32 tensor, folded into *slot as
+// the magnitude's bit pattern (ordered like the floats; a NaN ranks above everything, split3.h).  Runs on a few dozen blocks once per
+// net, never on the inference path.
+__global__ __launch_bounds__(256) void amax_f32_kernel(const float *__restrict__ x, size_t n4, unsigned *slot)
+{
+    __shared__ unsigned part[4];
+    float amax = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
+        amax = sat_amax4(amax, *reinterpret_cast<const f32x4 *>(x + i * 4));
+    unsigned b = sat_bits(amax);
+    for (int o = 32; o > 0; o >>= 1) b = max(b, (unsigned)__shfl_xor((int)b, o));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(slot, max(max(part[0], part[1]), max(part[2], part[3])));
+}
+
+hipError_t launch_amax_f32(hipStream_t s, const float *x, size_t n, unsigned *slot)
+{
+    const size_t n4 = n / 4;
+    const unsigned grid = (unsigned)((n4 + 255) / 256 > 1024 ? 1024 : (n4 + 255) / 256);
+    if (n4) hipLaunchKernelGGL(amax_f32_kernel, dim3(grid), dim3(256), 0, s, x, n4, slot);
+    return hipGetLastError();
+}
+
 hipError_t launch_multipool_concat(hipStream_t s, const float *x5, float *x6, int N, unsigned short *x6_s3, size_t s3_stride, int fmt, unsigned *sat)
 {
     hipLaunchKernelGGL(multipool_concat_kernel, dim3(N * 2), dim3(256), 0, s, x5, ActOut{x6, x6_s3, s3_stride, fmt, sat});

@@ -38,6 +38,16 @@ struct Graph {
     bool h2() const { return c->precision == 2; }
     int fmt() const { return c->precision; }           // split3.h: 0 fp32, 1 split-3, 2 split-2
     unsigned *sat() const { return h2() ? c->d_sat : nullptr; }   // f16x3: the context's sticky saturation flag
+    // f16x3 activation scales (pmp_host.h: NetWeights::act_exp): the segment the graph is in, and the exponent a segment's tensors carry
+    int seg = 0;
+    int E(int sg) const { return h2() ? w.act_exp[sg] : 0; }
+    // calibration pass (fp32 datapath, pmp_api.cpp: calibrate_mtt): the largest |value| of a tensor just produced, per launch
+    void note(const Act &a, const std::string &name, int sg)
+    {
+        if (!c->cal_on || !live() || a.split || (int)c->cal_log.size() >= PMP_CAL_SLOTS) return;
+        check(launch_amax_f32(c->stream, a.p, (size_t)n * a.C * a.H * a.W, c->d_cal + c->cal_log.size()), "amax");
+        c->cal_log.emplace_back(name, sg);
+    }
 
     // Tensors are sized for the n blocks of this pass (not for the chunk) and give their bytes back with release().
     Act alloc(int C, int H, int W, bool split)
@@ -85,8 +95,9 @@ struct Graph {
     }
 
     // One convolution of a residual block on the MFMA path of the active datapath.
+    // xexp: an extra power of two on the accumulator's way out (f16x3: the step between two segments' activation scales at a gate product)
     void conv(const Act &x, const RBWeights &r, bool second, const Act *sc_src, const Act *res, const Act *gate, bool pool,
-              Act &out, double flops, int cls)
+              Act &out, double flops, int cls, int xexp = 0)
     {
         if (!live()) return;
         KScope ks(c, cls, flops);
@@ -94,7 +105,7 @@ struct Graph {
             ConvX6Args a{};
             a.x = x.s(); a.x_stride = x.stride;
             if (h2()) {
-                a.w = second ? r.w2h : r.w0h; a.out_scale = std::ldexp(1.f, -(second ? r.k2 : r.k0)); a.sat = sat();
+                a.w = second ? r.w2h : r.w0h; a.out_scale = std::ldexp(1.f, xexp - (second ? r.k2 : r.k0)); a.sat = sat();
                 abl_conv_args(c, r, second, a);
             }
             else a.w = second ? r.w2x : r.w0x;
@@ -145,6 +156,8 @@ struct Graph {
                 else b.res = x.p;
                 { KScope ks(c, K_SMALL, 2.0 * px * r.cout * (r.cout * r.k * r.k + (r.has_sc ? r.cin : 0))); check(launch_conv_direct(c->stream, b), "conv_direct"); }
             }
+            note(t, name + ".t", seg);
+            note(y, name, seg);
             release(t);
             if (consume) release(x_in);
             return y;
@@ -158,8 +171,13 @@ struct Graph {
         const bool in_place = x_dead && !r.has_sc && !pool && x.split == y_split && x.C == ((r.cout + 15) & ~15);
         Act y = in_place ? x : alloc(r.cout, pool ? H / 2 : H, pool ? W / 2 : W, y_split);
         conv(x, r, false, nullptr, nullptr, nullptr, false, t, 2.0 * px * r.cout * r.cin * r.k * r.k, kclass(r.k, r.cin, r.cout));
+        note(t, name + ".t", seg);
+        // a gated block ends its attention segment: its output is (this segment) x (the gate operand, a trunk tensor of segment 0) and
+        // opens the next segment - the three exponents meet in the out_scale of the convolution whose epilogue multiplies
         conv(t, r, true, r.has_sc ? &x : nullptr, r.has_sc ? nullptr : &x, gate, pool, y,
-             2.0 * px * r.cout * (r.cout * r.k * r.k + (r.has_sc ? r.cin : 0)), kclass(r.k, r.cout, r.cout));
+             2.0 * px * r.cout * (r.cout * r.k * r.k + (r.has_sc ? r.cin : 0)), kclass(r.k, r.cout, r.cout),
+             gate ? E(seg) + E(0) - E(seg + 1) : 0);
+        note(y, name, gate ? seg + 1 : seg);
         release(t);
         if (x_dead && !in_place) release(x);
         return y;
@@ -170,12 +188,15 @@ struct Graph {
         const int S = luma ? 64 : 32;
         Act o = alloc(32, S, S, x6());     // bf16x6 mode: the stem writes split-3 planes directly
         if (!live()) return o;
-        StemArgs a{by, bu, bv, q, w.stem_w, w.stem_b, o.split ? nullptr : o.p, n, o.split ? o.s() : nullptr, o.stride, fmt(),
-                   h2() ? w.stem_wh : nullptr, std::ldexp(1.f, -w.stem_k), sat()};
+        // f16x3 MTT stems write segment 0 at its activation scale: 2^-e0 on the output scale and on the biases (stem_b_h)
+        const int e0 = msbd ? E(0) : 0;
+        StemArgs a{by, bu, bv, q, w.stem_w, (h2() && msbd && w.stem_b_h) ? w.stem_b_h : w.stem_b, o.split ? nullptr : o.p, n, o.split ? o.s() : nullptr, o.stride, fmt(),
+                   h2() ? w.stem_wh : nullptr, std::ldexp(1.f, -w.stem_k - e0), sat()};
         const int cin = (luma ? 1 : 3) + (msbd ? 1 : 0), k1 = luma ? 9 : 5, k2 = luma ? 5 : 3;
         const double macs = msbd ? (double)cin * (k1 * k1 * 16 + 2 * k1 * k2 * 8) : (double)cin * k1 * k1 * 32;
         KScope ks(c, K_STEM, 2.0 * n * S * S * macs);
         check(launch_stem(c->stream, luma, msbd, a), "stem");
+        note(o, "stem", seg);
         return o;
     }
 
@@ -191,10 +212,13 @@ struct Graph {
         return true;
     }
 
+    // f16x3 MTT heads read a tensor that carries its segment's activation scale: their weights hold the way back (head_w_h = head_w * 2^e)
+    const float *head_weights(int slot, int layer) const { return (h2() && layer >= 0 && w.head_w_h[slot]) ? w.head_w_h[slot] : w.head_w[slot]; }
+
     void head(const Act &x, int slot, int layer, float *qt, float *bt, float *dire)
     {
         if (!live()) return;
-        HeadArgs a{x.p, w.head_w[slot], w.head_b[slot], qt, bt, dire, n, x.H, layer};
+        HeadArgs a{x.p, head_weights(slot, layer), w.head_b[slot], qt, bt, dire, n, x.H, layer};
         KScope ks(c, K_SMALL, 2.0 * n * x.H * x.W * 72.0 * (layer < 0 ? 1 : 2));
         check(launch_head(c->stream, a), "head");
     }
@@ -263,7 +287,8 @@ int forward_msbd(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, 
         for (int i = 0; i < 2 && ok; ++i) ok = g.c16rb("trunk_Att1." + std::to_string(i), a.att[i], flops, 256);
         if (!ok) return g.rc;
         a.x5 = x5.s(); a.x5_stride = x5.stride; a.qt = qt; a.bt = bt; a.dire = dire; a.N = n; a.sat = g.sat();
-        for (int i = 0; i < 2; ++i) { a.head_w[i] = w.head_w[i]; a.head_b[i] = w.head_b[i]; }
+        a.att[1].s2 = std::ldexp(a.att[1].s2, g.E(1) + g.E(0) - g.E(2));     // the gate product x5 * att0: from segments 1 and 0 into segment 2
+        for (int i = 0; i < 2; ++i) { a.head_w[i] = g.head_weights(i, i); a.head_b[i] = w.head_b[i]; }
         if (g.live()) {
             KScope ks(c, K_CONV_OTHER, flops);
             g.check(launch_msbd_branch16(c->stream, a), "msbd_branch16");
@@ -277,14 +302,17 @@ int forward_msbd(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, 
         g.head(b, 0, 0, nullptr, bt, dire);
         g.release(b);
         // attention 1 gates x5 (:140-143), branch B2 -> out1 (accumulated in the head kernel, :146)
+        g.seg = 1;
         Act ai = g.alloc(16, 16, 16, g.x6());
         if (g.live()) {
             KScope ks(c, K_SMALL, 0.0);
             g.check(launch_att_input(c->stream, qt, bt, dire, 0, ai.split ? nullptr : ai.p, n, 16, ai.split ? ai.s() : nullptr, ai.stride, g.fmt(), g.sat()), "att_input");
         }
+        g.note(ai, "att_input1", 1);
         Act a1 = g.rb(ai, "trunk_Att1.0");
         Act xb1 = g.rb(a1, "trunk_Att1.1", false, &x5);
         g.release(x5);
+        g.seg = 2;
         b = g.rb(xb1, "trunk_B2.0");
         b = g.rb(b, "trunk_B2.1");
         b = g.rb(b, "trunk_B2.2", false, nullptr, true);
@@ -292,14 +320,17 @@ int forward_msbd(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, 
         g.release(b);
     }
     // attention 2 gates x4 at 32x32 (:147-150), branch B3 -> pool -> out2 (:151-153)
+    g.seg = 3;
     Act aj = g.alloc(16, 32, 32, g.x6());
     if (g.live()) {
         KScope ks(c, K_SMALL, 0.0);
         g.check(launch_att_input(c->stream, qt, bt, dire, 1, aj.split ? nullptr : aj.p, n, 32, aj.split ? aj.s() : nullptr, aj.stride, g.fmt(), g.sat()), "att_input");
     }
+    g.note(aj, "att_input2", 3);
     Act a2 = g.rb(aj, "trunk_Att2.0");
     Act xb3 = g.rb(a2, "trunk_Att2.1", false, &x4);
     g.release(x4);
+    g.seg = 4;
     b = g.rb(xb3, "trunk_B3.0");
     b = g.rb(b, "trunk_B3.1");
     b = g.rb(b, "trunk_B3.2", true, nullptr, true);

@@ -135,11 +135,127 @@ static int run_graph(pmp_ctx *c, F &&fwd)
     return fwd();
 }
 
+// ---- calibration of the f16x3 activation scales (pmp_host.h: NetWeights::act_exp; include/pmp.h) -------------------------------------
+// The library's own calibration content: PMP_CAL_BLOCKS blocks that span what 8-bit pictures can do to a first layer - flat black and
+// white, 1- and 2-pixel checkerboards, stripes, step edges, white noise, and smooth random content of three grain sizes (the kind
+// recipe R makes).  Deterministic (a 64-bit LCG), so every context, rank and run derives the same exponents from the same weights.
+constexpr int PMP_CAL_BLOCKS = 32;
+constexpr int PMP_CAL_TARGET_EXP = 12;      // a segment whose calibration maximum exceeds 2^12 is scaled down to it: 16x headroom to 65504
+
+static void make_calibration_blocks(std::vector<uint8_t> &y, std::vector<uint8_t> &u, std::vector<uint8_t> &v)
+{
+    y.assign((size_t)PMP_CAL_BLOCKS * 68 * 68, 0); u.assign((size_t)PMP_CAL_BLOCKS * 34 * 34, 0); v.assign((size_t)PMP_CAL_BLOCKS * 34 * 34, 0);
+    unsigned long long st = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (unsigned)(st >> 33); };
+    auto fill = [&](uint8_t *p, int S, int kind, int b) {
+        if (kind < 10) {
+            for (int r = 0; r < S; ++r)
+                for (int c = 0; c < S; ++c) {
+                    int val = 0;
+                    switch (kind) {
+                    case 0: val = 0; break;
+                    case 1: val = 255; break;
+                    case 2: val = ((r + c) & 1) ? 255 : 0; break;                 // 1-px checkerboard
+                    case 3: val = (((r >> 1) + (c >> 1)) & 1) ? 255 : 0; break;   // 2-px checkerboard
+                    case 4: val = (c & 1) ? 255 : 0; break;                       // vertical stripes, period 2
+                    case 5: val = ((r >> 1) & 1) ? 255 : 0; break;                // horizontal stripes, period 4
+                    case 6: val = c < S / 2 ? 0 : 255; break;                     // vertical step edge
+                    case 7: val = r < S / 2 ? 255 : 0; break;                     // horizontal step edge
+                    case 8: val = (((r >> 2) + (c >> 2)) & 1) ? 235 : 16; break;  // 4-px checkerboard, video range
+                    default: val = (r * 255) / (S - 1); break;                    // ramp
+                    }
+                    p[r * S + c] = (uint8_t)val;
+                }
+        } else if (kind < 14) {
+            for (int i = 0; i < S * S; ++i) p[i] = (uint8_t)(rnd() & 255);      // white noise
+        } else {   // smooth random: bilinear interpolation of a coarse random grid (grain 4, 8 or 16 px) + a little noise
+            const int grain = 4 << (b % 3), G = S / grain + 2;
+            std::vector<int> grid((size_t)G * G);
+            for (auto &gv : grid) gv = (int)(rnd() & 255);
+            for (int r = 0; r < S; ++r)
+                for (int c = 0; c < S; ++c) {
+                    const int gy = r / grain, gx = c / grain, fy = r % grain, fx = c % grain;
+                    const int a00 = grid[gy * G + gx], a01 = grid[gy * G + gx + 1], a10 = grid[(gy + 1) * G + gx], a11 = grid[(gy + 1) * G + gx + 1];
+                    int val = (a00 * (grain - fy) * (grain - fx) + a01 * (grain - fy) * fx + a10 * fy * (grain - fx) + a11 * fy * fx) / (grain * grain);
+                    val += (int)(rnd() % 13) - 6;
+                    p[r * S + c] = (uint8_t)(val < 0 ? 0 : val > 255 ? 255 : val);
+                }
+        }
+    };
+    for (int b = 0; b < PMP_CAL_BLOCKS; ++b) {
+        fill(y.data() + (size_t)b * 68 * 68, 68, b, b);
+        fill(u.data() + (size_t)b * 34 * 34, 34, b, b + 1);
+        fill(v.data() + (size_t)b * 34 * 34, 34, b, b + 2);
+    }
+}
+
+// Runs the (QT, MTT) pair of a component once on the calibration blocks - on the fp32 MFMA datapath, launch per layer, with the largest
+// |value| of every MTT tensor recorded (nets.cpp: Graph::note) - and derives the segment exponents of the f16x3 datapath from them:
+// e = the smallest exponent >= 0 that brings the segment's maximum to 2^PMP_CAL_TARGET_EXP or below.  The attention trunks (segments
+// 1 and 3) start from logits and keep e = 0.  Synchronises the stream (once per net: first use on the f16x3 datapath).
+static int calibrate_mtt(pmp_ctx *c, bool luma, NetWeights &wq, NetWeights &wb)
+{
+    int rc;
+    if ((rc = ensure_datapath(c, wq, PMP_PRECISION_F32)) != PMP_OK || (rc = ensure_datapath(c, wb, PMP_PRECISION_F32)) != PMP_OK) return rc;
+    static std::vector<uint8_t> hy, hu, hv;
+    static std::once_flag once;
+    std::call_once(once, [] { make_calibration_blocks(hy, hu, hv); });
+    const int n = PMP_CAL_BLOCKS;
+    const size_t o_u = ((size_t)n * 68 * 68 + 255) & ~(size_t)255, o_v = o_u + (((size_t)n * 34 * 34 + 255) & ~(size_t)255);
+    const size_t o_q = o_v + (((size_t)n * 34 * 34 + 255) & ~(size_t)255), o_bt = o_q + (size_t)n * 64 * 4, o_dr = o_bt + (size_t)n * 768 * 4;
+    if ((rc = ensure(c, c->d_calbuf, o_dr + (size_t)n * 768 * 4)) != PMP_OK) return rc;
+    hipError_t e = hipSuccess;
+    if (!c->d_cal) e = hipMalloc((void **)&c->d_cal, PMP_CAL_SLOTS * sizeof(unsigned));
+    char *base = static_cast<char *>(c->d_calbuf.p);
+    if (e == hipSuccess) e = hipMemcpyAsync(base, hy.data(), hy.size(), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(base + o_u, hu.data(), hu.size(), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(base + o_v, hv.data(), hv.size(), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_cal, 0, PMP_CAL_SLOTS * sizeof(unsigned), c->stream);
+    if (e != hipSuccess) return hip_fail(c, e, "calibration: staging");
+    const uint8_t *dy = (const uint8_t *)base, *du = (const uint8_t *)(base + o_u), *dv = (const uint8_t *)(base + o_v);
+    float *dq = (float *)(base + o_q), *dbt = (float *)(base + o_bt), *ddr = (float *)(base + o_dr);
+    const int saved = c->precision;
+    c->precision = PMP_PRECISION_F32;
+    c->cal_log.clear();
+    rc = run_graph(c, [&] { return forward_q(c, luma, wq, dy, du, dv, n, dq); });
+    c->cal_on = 1;
+    if (rc == PMP_OK) rc = run_graph(c, [&] { return forward_msbd(c, luma, wb, dy, du, dv, dq, n, dbt, ddr); });
+    c->cal_on = 0;
+    c->precision = saved;
+    if (rc != PMP_OK) return rc;
+    std::vector<unsigned> bits(PMP_CAL_SLOTS);
+    e = hipMemcpyAsync(bits.data(), c->d_cal, PMP_CAL_SLOTS * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return hip_fail(c, e, "calibration: maxima");
+    float seg_max[5] = {0, 0, 0, 0, 0};
+    wb.cal_names.clear(); wb.cal_seg.clear(); wb.cal_amax.clear();
+    for (size_t i = 0; i < c->cal_log.size(); ++i) {
+        float m;
+        std::memcpy(&m, &bits[i], 4);
+        wb.cal_names.push_back(c->cal_log[i].first); wb.cal_seg.push_back(c->cal_log[i].second); wb.cal_amax.push_back(m);
+        const int sg = c->cal_log[i].second;
+        if (sg >= 0 && sg < 5 && (m > seg_max[sg] || m != m)) seg_max[sg] = m;
+    }
+    int exps[5] = {0, 0, 0, 0, 0};
+    for (int sg = 0; sg < 5; sg += 2) {        // a NaN / inf maximum leaves e = 0: that net needs the range guard's fp32 re-run anyway
+        const float m = seg_max[sg];
+        if (!(m == m) || std::isinf(m)) continue;
+        int ex = 0;
+        while (ex < 60 && m > std::ldexp(1.f, PMP_CAL_TARGET_EXP + ex)) ++ex;
+        exps[sg] = ex;
+    }
+    if ((rc = set_activation_scales(c, wb, exps)) != PMP_OK) return rc;
+    wb.calibrated = true;
+    return PMP_OK;
+}
+
 static int infer_passes(pmp_ctx *c, bool luma, NetWeights &wq, NetWeights &wb, const uint8_t *by, const uint8_t *bu,
                         const uint8_t *bv, int64_t n, float *qt, float *bt, float *dire)
 {
     int rc0;     // weights are packed per datapath, on first use (the load packed the datapath that was current then)
     if ((rc0 = ensure_datapath(c, wq, c->precision)) != PMP_OK || (rc0 = ensure_datapath(c, wb, c->precision)) != PMP_OK) return rc0;
+    // f16x3: the MTT net's activation scales, from one calibration pass when the net is first used on this datapath
+    if (c->precision == PMP_PRECISION_F16X3 && !wb.calibrated && (rc0 = calibrate_mtt(c, luma, wq, wb)) != PMP_OK) return rc0;
     if ((rc0 = abl_prepare_pass(c, wq, wb)) != PMP_OK) return rc0;
     // Overlap mode: a call of at least 1024 blocks runs as (at least) two chunks, even ones on the context's stream and workspace, odd
     // ones on a second stream with a second workspace, so that one chunk's small launches (stems, 16x16 tails, HBM-bound 32x32 layers)
@@ -430,6 +546,8 @@ int pmp_destroy(pmp_ctx *c)
                       &c->d_out[0], &c->d_out[1], &c->d_out[2], &c->d_out[3], &c->d_frames[0], &c->d_frames[1], &c->d_frames[2]};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     if (c->d_sat) hipFree(c->d_sat);
+    if (c->d_cal) hipFree(c->d_cal);
+    if (c->d_calbuf.p) hipFree(c->d_calbuf.p);
     if (c->h_sat) hipHostFree(c->h_sat);
     if (c->stream2) hipStreamDestroy(c->stream2);
     hipStreamDestroy(c->own_stream);
@@ -763,6 +881,34 @@ int pmp_debug_set_fusion(pmp_ctx *c, int on)
     if (rc != PMP_OK) return rc;
     c->fuse16 = on ? 1 : 0;
     return PMP_OK;
+}
+
+int pmp_debug_activation_report(pmp_ctx *c, int comp, int qp, int exps[5], float seg_amax[5], char *buf, int64_t cap)
+{
+    CHECK_CTX(c);
+    if (comp != PMP_LUMA && comp != PMP_CHROMA) return set_err(c, PMP_E_INVALID, "pmp_debug_activation_report: bad comp");
+    const bool luma = comp == PMP_LUMA;
+    NetWeights *wq = find_net(c, luma ? PMP_NET_LUMA_Q : PMP_NET_CHROMA_Q, qp), *wb = find_net(c, luma ? PMP_NET_LUMA_MSBD : PMP_NET_CHROMA_MSBD, qp);
+    if (!wq || !wb) return set_err(c, PMP_E_NOWEIGHTS, "pmp_debug_activation_report: weights for this (comp, qp) are not loaded");
+    int rc = settle(c);
+    if (rc != PMP_OK) return rc;
+    if (!wb->calibrated && (rc = calibrate_mtt(c, luma, *wq, *wb)) != PMP_OK) return rc;
+    std::string out;
+    float sm[5] = {0, 0, 0, 0, 0};
+    for (size_t i = 0; i < wb->cal_names.size(); ++i) {
+        char line[160];
+        std::snprintf(line, sizeof line, "%s %d %.9g\n", wb->cal_names[i].c_str(), wb->cal_seg[i], (double)wb->cal_amax[i]);
+        out += line;
+        const int sg = wb->cal_seg[i];
+        if (sg >= 0 && sg < 5 && (wb->cal_amax[i] > sm[sg] || wb->cal_amax[i] != wb->cal_amax[i])) sm[sg] = wb->cal_amax[i];
+    }
+    for (int i = 0; i < 5; ++i) { if (exps) exps[i] = wb->act_exp[i]; if (seg_amax) seg_amax[i] = sm[i]; }
+    if (buf && cap > 0) {
+        const size_t k = std::min((size_t)cap - 1, out.size());
+        std::memcpy(buf, out.data(), k);
+        buf[k] = 0;
+    }
+    return (int)wb->cal_names.size();
 }
 
 int pmp_debug_set_winograd(pmp_ctx *c, int on)

@@ -48,6 +48,22 @@ struct NetWeights {
     unsigned short *stem_wh = nullptr; int stem_k = 0; // f16x3 MFMA stem: fragment stream, scaled by 2^stem_k
     float *head_w[3] = {nullptr, nullptr, nullptr};    // [9][8][cout]
     float *head_b[3] = {nullptr, nullptr, nullptr};
+    // f16x3 ACTIVATION SCALES (MTT nets; include/pmp.h).  The net is bias-free behind its stems and ReLU, max-pool and the gate product are
+    // positively homogeneous, so a tensor may travel as true * 2^-e - exactly, a power of two commutes with every rounding - as long as
+    // whoever consumes it knows e.  One exponent per SEGMENT of the graph (Model_QBD.py:127-155):
+    //   0  stem .. trunk_M1 .. trunk_M2 .. trunk_B1          1  attention trunk 1 (its input is built from logits: e = 0)
+    //   2  x5 * att0 .. trunk_B2                              3  attention trunk 2 (e = 0)          4  x4 * att1 .. trunk_B3
+    // and the changes of scale cost nothing at run time: 2^-e0 is folded into the stem's output scale and biases (stem_b_h), the step at a
+    // gate product into the out_scale of the convolution whose epilogue multiplies (nets.cpp), the way back into the head weights
+    // (head_w_h = head_w * 2^e).  The exponents come from a calibration pass on the library's own extreme-content blocks, run once when
+    // the net is first used on the f16x3 datapath (pmp_api.cpp: calibrate_mtt); all zero = the arithmetic of a net without scales, bit for bit.
+    int act_exp[5] = {0, 0, 0, 0, 0};
+    bool calibrated = false;
+    float *stem_b_h = nullptr;                         // f16x3: stem biases * 2^-act_exp[0]
+    float *head_w_h[3] = {nullptr, nullptr, nullptr};  // f16x3: head weights * 2^act_exp[{0, 2, 4}]
+    std::vector<std::string> cal_names;                // calibration record: tensors in launch order ...
+    std::vector<int> cal_seg;                          // ... their segment ...
+    std::vector<float> cal_amax;                       // ... and their largest |value| (true scale) on the calibration blocks
     std::vector<void *> allocs;
 };
 
@@ -134,6 +150,12 @@ struct pmp_ctx {
     int overlap = 0;                       // two chunks in flight on two streams (PMP_OVERLAP=1 in the environment at pmp_create)
     size_t ws_need = 0;                    // what the largest pass so far needed of it (pmp_get_workspace_bytes)
     pmp::DevBuf d_in[3], d_logit[3], d_out[4], d_frames[3];  // staging for the host-pointer entry points
+    // calibration of the f16x3 activation scales (NetWeights::act_exp): while cal_on, the graph (nets.cpp, running on the fp32 datapath) folds
+    // the largest |value| of every tensor it produces into d_cal[slot] and logs (name, segment) per slot
+    int cal_on = 0;
+    unsigned *d_cal = nullptr;             // PMP_CAL_SLOTS device words
+    std::vector<std::pair<std::string, int>> cal_log;
+    pmp::DevBuf d_calbuf;                  // calibration blocks and their logits
     // kernel-class timing
     uint32_t kmask = 0;
     std::vector<pmp::KTimeRec> krec[pmp::K_NCLASS];
@@ -151,6 +173,9 @@ int hip_fail(pmp_ctx *c, hipError_t e, const char *what);
 int load_net_weights(pmp_ctx *c, int net_id, int qp, const float *blob, const pmp_tensor_desc *descs, int ndesc);
 int ensure_datapath(pmp_ctx *c, NetWeights &w, int precision);   // packs the formats of `precision` if the net does not hold them yet
 void free_net_weights(NetWeights &w);
+// f16x3 activation scales: stores exps in w.act_exp and (re)builds the scaled stem biases and head weights on the device
+int set_activation_scales(pmp_ctx *c, NetWeights &w, const int exps[5]);
+constexpr int PMP_CAL_SLOTS = 128;
 
 // nets.cpp: forward graphs on device pointers (n <= chunk); all launches go to c->stream.
 int forward_q(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, const uint8_t *bu, const uint8_t *bv,

@@ -133,6 +133,10 @@ hipError_t launch_multipool_concat(hipStream_t s, const float *x5, float *x6, in
 hipError_t launch_att_input(hipStream_t s, const float *q, const float *bt, const float *dire, int layer, float *out,
                             int N, int S, unsigned short *out_s3 = nullptr, size_t s3_stride = 0, int fmt = 1, unsigned *sat = nullptr);
 
+// Largest |value| of an fp32 tensor (n a multiple of 4), atomicMax'ed into *slot as the bit pattern of the magnitude: the calibration
+// pass of the f16x3 activation scales (pmp_api.cpp: calibrate_mtt).
+hipError_t launch_amax_f32(hipStream_t s, const float *x, size_t n, unsigned *slot);
+
 // ------------------------------------------------------------------------------------------------ post-processing
 // eli_structual_error + Map_to_Partition, one wavefront per block.  qt raw logits [N][64]; bt, dire [N][3][256].
 // record_stride != 0: the four outputs are fields of one packed record per block (bytes between blocks), else dense arrays.

@@ -274,6 +274,44 @@ int load_net_weights(pmp_ctx *c, int net_id, int qp, const float *blob, const pm
     return PMP_OK;
 }
 
+// f16x3 activation scales of an MTT net (pmp_host.h: NetWeights::act_exp): the scaled copies of the tensors that carry the changes of
+// scale - stem biases * 2^-e0 (the stem's output scale takes the same factor in nets.cpp), head weights * 2^e of the segment the head reads.
+// Powers of two: every product and sum of the scaled net is the unscaled one times a power of two, exactly.
+int set_activation_scales(pmp_ctx *c, NetWeights &nw, const int exps[5])
+{
+    if (nw.net_id != PMP_NET_LUMA_MSBD && nw.net_id != PMP_NET_CHROMA_MSBD) return set_err(c, PMP_E_INVALID, "activation scales: MTT nets only");
+    Blob b{nw.host.data(), nw.descs.data(), (int)nw.descs.size()};
+    std::vector<float> stage;
+    int rc;
+    const float *bias[3];
+    static const char *stems[3] = {"conv_b1_1.bias", "conv_b1_2.bias", "conv_b1_3.bias"};
+    static const int nb[3] = {16, 8, 8};
+    for (int i = 0; i < 3; ++i) {
+        if ((rc = need(c, b, stems[i], {nb[i]}, &bias[i]))) return rc;
+        for (int j = 0; j < nb[i]; ++j) stage.push_back(std::ldexp(bias[i][j], -exps[0]));
+    }
+    static const char *heads[3] = {"conv_B1.weight", "conv_B2.weight", "conv_B3.weight"};
+    for (int k = 0; k < 3; ++k) {
+        const float *w;
+        if ((rc = need(c, b, heads[k], {2, 8, 3, 3}, &w))) return rc;
+        std::vector<float> p = pack_plain(w, 2, 8, 3, 3);
+        for (float v : p) stage.push_back(std::ldexp(v, exps[2 * k]));
+    }
+    const size_t nhead = (stage.size() - 32) / 3;
+    if (!nw.stem_b_h) {
+        void *d = nullptr;
+        hipError_t e = hipMalloc(&d, stage.size() * sizeof(float));
+        if (e != hipSuccess) return hip_fail(c, e, "hipMalloc(activation scales)");
+        nw.allocs.push_back(d);
+        nw.stem_b_h = static_cast<float *>(d);
+        for (int k = 0; k < 3; ++k) nw.head_w_h[k] = nw.stem_b_h + 32 + k * nhead;
+    }
+    hipError_t e = hipMemcpy(nw.stem_b_h, stage.data(), stage.size() * sizeof(float), hipMemcpyHostToDevice);   // synchronous: nothing in flight reads an uncalibrated net's copies
+    if (e != hipSuccess) return hip_fail(c, e, "hipMemcpy(activation scales)");
+    for (int i = 0; i < 5; ++i) nw.act_exp[i] = exps[i];
+    return PMP_OK;
+}
+
 int ensure_datapath(pmp_ctx *c, NetWeights &nw, int precision)
 {
     const unsigned bit = 1u << precision;

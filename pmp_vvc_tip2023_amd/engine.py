@@ -99,6 +99,18 @@ class Engine:
     def clear_saturation(self):
         self._ck(self.lib.pmp_clear_saturation(self.h))
 
+    def activation_report(self, comp, qp):
+        """f16x3 activation scales of the MTT net of (comp, qp) and the calibration record behind them (include/pmp.h):
+        {"exps": [e0..e4], "seg_amax": [..5..], "tensors": [(name, segment, max |value|), ...]}.  Loads the pair if necessary."""
+        self.load(comp, qp)
+        exps = (C.c_int * 5)()
+        amax = (C.c_float * 5)()
+        buf = C.create_string_buffer(16384)
+        n = self._ck(self.lib.pmp_debug_activation_report(self.h, COMP_ID[comp], int(qp), exps, amax, buf, len(buf)))
+        rows = [ln.split() for ln in buf.value.decode().splitlines()]
+        assert len(rows) == n
+        return {"exps": list(exps), "seg_amax": list(amax), "tensors": [(r[0], int(r[1]), float(r[2])) for r in rows]}
+
     def synchronize(self):
         self._ck(self.lib.pmp_synchronize(self.h))
 
