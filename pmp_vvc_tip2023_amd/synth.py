@@ -109,7 +109,7 @@ def synth_msbd_weights(comp, seed):
 #   1. bootstrap (seeded resampling, pure integer indexing): every output channel of an MTT conv tensor picks a donor output channel of
 #      a real tensor with the same kernel size and fills its input slices from that donor's row, so the k x k filters, their
 #      magnitudes and the per-channel structure are the trained ones (the stems' 5x9 / 9x5 / 3x5 / 5x3 kernels are centre crops of real
-#      9x9 / 5x5 stem filters; the plane that carries the QT logits - values 0..3 instead of 0..255 - gets a real filter x 32);
+#      9x9 / 5x5 stem filters; the plane that carries the QT logits gets a real filter too, see _TL_Q_STEM);
 #   2. one scalar per tensor (trained_like_scales.json, written by tools/calibrate_trained_like.py in the build container from the
 #      reference's own modules on recipe-R blocks) so that the trunks run at the QT nets' activation range (stem max ~ 4e2, x4 / x5
 #      max ~ 1e3..2e3), both attention gates have rms 1, and the heads spread over the depth / direction ranges Map2Partition works on.
@@ -118,6 +118,13 @@ def synth_msbd_weights(comp, seed):
 # Stress knobs, exact for powers of two (the nets are bias-free behind the stems and ReLU is positively homogeneous, so the oracle's
 # logits do not change): trunk_gain K multiplies the stems (trunk activations x K), gate_gain G the last block of both attention trunks
 # (gates x G); the heads are divided by K (conv_B1) and K*G (conv_B2, conv_B3).
+# How hard the MTT nets lean on the raw QT logits q they take as input (a stem plane, channel 0 of both attention trunks).  q arrives with
+# the QT net's own error (Luma_Q: up to 8e-4 between any two fp32 evaluations), and north_star's 1e-3 on the MTT logits
+# can only hold end to end if the MTT net does not amplify it: with a real stem filter x 32 on the q plane (to weigh 0..3 against 0..255)
+# and unweighted attention inputs the bootstrapped nets amplified a perturbation of q 10..30x, measured with the oracle; with the
+# two factors below 0.5..1.7x, as the uniform nets (0.8..2.1x).
+_TL_Q_STEM = 1.0
+_TL_Q_ATT = 0.125
 _TL_SCALES = None
 
 
@@ -190,10 +197,13 @@ def trained_like_raw(comp, qp, weight_dir=None):
             co, ci, kh, kw = shape
             full = _tl_resample(stem_pool, (co, ci, ks, ks), qp, key)    # pixel planes: real stem filters
             logit = _tl_resample(stem_pool, (co, 1, ks, ks), qp, key + "/q")
-            full[:, ci - 1] = logit[:, 0] * np.float32(32.0)              # last plane = the upsampled QT logits (Model_QBD.py:131)
+            full[:, ci - 1] = logit[:, 0] * np.float32(_TL_Q_STEM)         # last plane = the upsampled QT logits (Model_QBD.py:131)
             out[name] = np.ascontiguousarray(_crop(full, kh, kw))
         else:
             out[name] = _tl_resample(pools[(shape[2], shape[3])], shape, qp, key)
+            if name in ("trunk_Att1.0.left.0.weight", "trunk_Att1.0.shortcut.0.weight",
+                        "trunk_Att2.0.left.0.weight", "trunk_Att2.0.shortcut.0.weight"):
+                out[name][:, 0] *= np.float32(_TL_Q_ATT)                   # input channel 0 of the attention trunks = up(q) (:140, :147)
     return out
 
 

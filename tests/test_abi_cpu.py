@@ -102,6 +102,23 @@ def test_binary_side_channel_equals_text(lib, comp, tmp_path, oracle_lib):
     assert np.array_equal(mh, th) and np.array_equal(mv, tv) and np.array_equal(mq, tq) and np.array_equal(md, td)
 
 
+def test_f16x3_weight_packing_of_huge_weights_stays_finite(lib):
+    """A tensor with weights of 8192 and more gets a NEGATIVE scale exponent (until round 5 the exponent was clamped at 0 and such weights
+    left the fp16 range when split: silent infinities in the weight stream)."""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    for peak in (9000.0, 3.0e6, 1.0e12):
+        w = (rng.standard_normal((16, 16, 3, 3)) * peak / 4).astype(np.float32)
+        w[3, 2, 1, 1] = peak
+        kexp = C.c_int(99)
+        n = lib.pmp_debug_pack_f16x3(w.ctypes.data_as(C.POINTER(C.c_float)), 16, 16, 3, None, 0, C.byref(kexp))
+        assert kexp.value < 0 and 4096.0 <= 2.0 ** kexp.value * np.abs(w).max() < 8192.0
+        out = np.zeros(n, np.uint16)
+        assert lib.pmp_debug_pack_f16x3(w.ctypes.data_as(C.POINTER(C.c_float)), 16, 16, 3, out.ctypes.data_as(C.POINTER(C.c_uint16)), n, C.byref(kexp)) == n
+        st = out.view(np.float16).astype(np.float64)
+        assert np.isfinite(st).all() and np.abs(st).max() < 8192.0
+
+
 @pytest.mark.parametrize("cout,cin,k", [(64, 64, 3), (32, 17, 5), (8, 32, 1), (64, 32, 5)])
 def test_f16x3_weight_packing_is_exact_to_22_bits(lib, cout, cin, k):
     """conv_f16x3.hip's weight stream (host code, no GPU): S = 2^k puts max|S*w| in [4096, 8192); every weight is

@@ -83,23 +83,38 @@ def test_trained_like_512_fresh_blocks_vs_oracle(eng, comp, qp):
     _load_tl(eng, comp, qp)
     eng.clear_saturation()
     qt, bt, dire = eng.inference_pre_QBD(comp, qp, y, u, v)
-    assert np.abs(qt - oq).max() < TOL
     # per block: north_star's absolute 1e-3 wherever the logits are in Map2Partition's operating range (|logit| <= 8: every natural block);
     # the synthetic extremes (2-px checkerboard: logits of +-300, white noise: +-75) get the same tolerance RELATIVE to their logits - the
-    # torch oracle itself is 6.6e-4 from an fp64 evaluation on the checkerboard block (tools/calibrate_trained_like.py notes)
-    e_blk = np.maximum(np.abs(bt - obt).max(axis=(1, 2, 3)), np.abs(dire - odire).max(axis=(1, 2, 3)))
-    mag = np.maximum(np.abs(obt).max(axis=(1, 2, 3)), np.abs(odire).max(axis=(1, 2, 3)))
-    tol = TOL * np.maximum(1.0, mag / 8.0)
+    # torch oracle itself is 6.6e-4 from an fp64 evaluation on the checkerboard block
+    def per_block(pairs):
+        e = np.max([np.abs(a - b).reshape(len(a), -1).max(axis=1) for a, b in pairs], axis=0)
+        m = np.max([np.abs(b).reshape(len(b), -1).max(axis=1) for _, b in pairs], axis=0)
+        return e, m, TOL * np.maximum(1.0, m / 8.0)
+    e_q, m_q, tol_q = per_block([(qt, oq)])
+    assert (e_q < tol_q).all(), "QT logits: block %d off by %g" % (int(np.argmax(e_q / tol_q)), e_q.max())
+    # (a) the MTT net ALONE on identical inputs: the oracle fed with the QT logits the HIP path produced
+    from oracle import nets_torch as O
+    from pmp_vvc_tip2023_amd import synth
+    luma = comp == "Luma"
+    x = O.luma_input(y) if luma else O.chroma_input(y, u, v)
+    with torch.no_grad():
+        o = O.msbd_forward(synth.trained_like_msbd_weights(comp, qp), x, torch.from_numpy(qt), luma)
+    abt = np.stack([t[:, 0].numpy() for t in o], 1); adire = np.stack([t[:, 1].numpy() for t in o], 1)
+    e_a, m_a, tol_a = per_block([(bt, abt), (dire, adire)])
+    assert (e_a < tol_a).all(), "%s QP%d MTT net on identical inputs: block %d off by %g" % (comp, qp, int(np.argmax(e_a / tol_a)), e_a[np.argmax(e_a / tol_a)])
+    # (b) end to end, QT net included: the oracle's own q feeds the oracle's MTT net (the trained-like nets pass an error of q on
+    # 0.5..1.7x, synth.py: _TL_Q_STEM)
+    e_blk, mag, tol = per_block([(bt, obt), (dire, odire)])
     worst = int(np.argmax(e_blk / tol))
-    print("trained-like %s QP%d %s: worst block %d: |logit - oracle| = %.2e at |logit| %.1f (natural blocks: max %.2e), reruns %d"
-          % (comp, qp, eng.get_precision(), worst, e_blk[worst], mag[worst], e_blk[4:].max(), eng.saturation_reruns()))
+    print("trained-like %s QP%d %s: MTT alone max %.2e | end to end worst block %d: %.2e at |logit| %.1f (natural blocks: max %.2e), reruns %d"
+          % (comp, qp, eng.get_precision(), e_a[4:].max(), worst, e_blk[worst], mag[worst], e_blk[4:].max(), eng.saturation_reruns()))
     assert (e_blk < tol).all(), "%s QP%d block %d off by %g (|logit| %g)" % (comp, qp, worst, e_blk[worst], mag[worst])
     assert (mag[4:] <= 16).all()                                  # the recipe-R blocks ARE in the operating range
     assert eng.saturation_reruns() == 0
 
 
 @pytest.mark.parametrize("comp,qp", [("Luma", 22), ("Chroma", 27)])
-@pytest.mark.parametrize("gains", [(64.0, 1.0), (1.0, 16.0), (64.0, 16.0), (1.0, 1024.0), (4096.0, 64.0)])
+@pytest.mark.parametrize("gains", [(64.0, 1.0), (1.0, 16.0), (64.0, 16.0), (1.0, 1024.0), (4096.0, 64.0), (65536.0, 256.0)])
 def test_trained_like_stress_gains_stay_on_the_default_datapath(eng, comp, qp, gains):
     """trunk_gain K / gate_gain G are exact powers of two that the heads undo (synth.py): the reference's logits do not change (pinned
     while the goldens were generated), but the trunks now run at K x 1e3 and the gated products at K x G x 1e4 - far outside fp16.
