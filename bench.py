@@ -89,6 +89,7 @@ def cpu_baseline(sample_blocks, seed, eng=None):
                      "C oracle post-processing (1 thread); the host has %d cores - the thread count is the fastest of {8, 16, 32, 64} "
                      "(capped at the core count) on an 8-block probe, because torch's CPU convolutions stop scaling on 64x64 maps "
                      "well below the core count (probe timings on stderr)" % (sample_blocks, seed, cores, ncpu)}
+    out["all_cores"] = cpu_all_cores(cores, ncpu, seed, best[1] / 8)
     parity = None
     if eng is not None:
         yb = np.ascontiguousarray(y[:sample_blocks])
@@ -105,6 +106,92 @@ def cpu_baseline(sample_blocks, seed, eng=None):
                                                          (gq8 != oq8.astype(gq8.dtype)).sum() + (gd8 != od8).sum()),
                   "flags_compared": int(ghor.size + gver.size + gq8.size + gd8.size)}
     return out, parity
+
+
+def cpu_worker(blocks, seed, threads):
+    """`bench.py --cpu-worker`: one process of the whole-host CPU baseline.  Torch CPU only (no GPU call).  Warms up, says
+    "ready", waits for "go" on stdin, runs the oracle on its own slice and prints its wall-clock window."""
+    from oracle import nets_torch as O, postproc as P
+    from pmp_vvc_tip2023_amd import synth, weights as W
+    torch.set_num_threads(threads)
+    y, _, _ = synth.recipe_r_blocks(blocks, seed)
+    wq, _ = W.load_net_weights("Luma_Q", 22)
+    wbd, _ = W.load_net_weights("Luma_MSBD", 22, allow_synthetic=True)
+    x = O.luma_input(y)
+    q, b, d = O.infer_qbd(wq, wbd, x[:8], True, batch=8)
+    P.seq_post_process(q, b, d, "Luma", 1, 64 * 8, 64, None)
+    print("ready", flush=True)
+    sys.stdin.readline()
+    t0 = time.time()
+    q, b, d = O.infer_qbd(wq, wbd, x, True, batch=64)
+    P.seq_post_process(q, b, d, "Luma", 1, 64 * blocks, 64, None)
+    print("done %.6f %.6f %d" % (t0, time.time(), blocks), flush=True)
+
+
+def cpu_all_cores(threads, ncpu, seed, s_per_block):
+    """What the WHOLE host does on the same workload: host_cores // threads fresh worker processes (torch CPU, `threads` threads each,
+    no GPU import), each on its own slice of recipe-R blocks, released together; blocks / (last end - first start).  `value` above
+    stays the single calibrated process for continuity; this is the box's actual CPU capacity for the path (blocks are independent,
+    so the reference's CPU path shards the same way)."""
+    import subprocess
+    procs_n = max(1, ncpu // max(threads, 1))
+    # ~15 s per worker at the single-process rate (workers slow each other down: shared caches, memory bandwidth)
+    blocks = max(16, min(256, int(15.0 / max(s_per_block, 1e-3)) // 8 * 8))
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", "%d,%d,%d" % (blocks, seed + 100 + i, threads)],
+                              stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True) for i in range(procs_n)]
+    try:
+        for p in procs:
+            if p.stdout.readline().strip() != "ready":
+                raise RuntimeError("a CPU worker did not come up")
+        for p in procs:
+            p.stdin.write("go\n"); p.stdin.flush()
+        wins = []
+        for p in procs:
+            tok = p.stdout.readline().split()
+            if len(tok) != 4 or tok[0] != "done":
+                raise RuntimeError("a CPU worker died")
+            wins.append((float(tok[1]), float(tok[2]), int(tok[3])))
+        for p in procs:
+            p.wait(timeout=30)
+    except Exception as e:      # noqa: BLE001 - a baseline that cannot be taken is reported as such, it never fails the bench
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        log("cpu_baseline: whole-host leg failed: %s" % e)
+        return {"error": str(e)}
+    wall = max(w[1] for w in wins) - min(w[0] for w in wins)
+    total = sum(w[2] for w in wins)
+    log("cpu_baseline: whole host: %d processes x %d threads, %d blocks in %.2f s" % (procs_n, threads, total, wall))
+    return {"processes": procs_n, "threads_each": threads, "cores_used": procs_n * threads, "host_cores": ncpu, "blocks": total,
+            "blocks_per_s": round(total / wall, 2), "value": round(total / 4.0 / wall, 3), "unit": "CTU/s", "wall_s": round(wall, 2),
+            "note": "fresh worker processes (torch CPU only), each the single-process configuration above on its own recipe-R slice, released "
+                    "together; rate = all blocks / (last end - first start)"}
+
+
+def trained_like_extra(eng, dev, n, step, timed):
+    """The same step with TRAINED-LIKE MTT weights (synth.trained_like_msbd_weights: tensors bootstrapped from the real QT-net tensors,
+    trunks at 1e3, gate products at 1e4) instead of the benign uniform ones: does the headline describe a net with trained-scale
+    activations?  Reports the step time, the f16x3 activation-scale exponents the library chose and the range guard's re-run count
+    (must be 0: a re-run is the 2.8x slower fp32 datapath).  Also at a stress setting (trunk x 64, gates x 16)."""
+    from pmp_vvc_tip2023_amd import synth
+    out = {}
+    for tag, gains in (("", {}), ("_stress_k64_g16", {"trunk_gain": 64.0, "gate_gain": 16.0})):
+        eng.load("Luma", 22, msbd_weights=synth.trained_like_msbd_weights("Luma", 22, **gains))
+        rep = eng.activation_report("Luma", 22)
+        eng.clear_saturation()
+        dt = timed(lambda: step("Luma", 22), 5)
+        eng.synchronize()
+        out["ms_per_step" + tag] = round(dt * 1e3, 3)
+        out["ctu_per_s" + tag] = round(n / 4.0 / dt, 2)
+        out["saturation_reruns" + tag] = eng.saturation_reruns()
+        out["activation_exps" + tag] = rep["exps"]
+        out["segment_amax" + tag] = [round(float(m), 1) for m in rep["seg_amax"]]
+    eng.load("Luma", 22, msbd_weights=synth.synth_msbd_weights("Luma", 22))      # back to the headline's weights
+    out["note"] = ("Luma QP22, device-resident step, 5 steps after 1 warm-up; MTT weights bootstrapped from the real Luma_Q/Chroma_Q tensors "
+                   "(tests/golden/g2b_msbd_trained_like.npz pins them against the reference modules); activation_exps = per-segment power-of-two "
+                   "activation scales chosen by the library's calibration pass (include/pmp.h); not used for `value`")
+    return out
 
 
 def measure_extras(eng, args, dev, n, y, u, v, step):
@@ -148,6 +235,9 @@ def measure_extras(eng, args, dev, n, y, u, v, step):
                                                  "bit-identical records; not used for `value`"},
                         "note": "device-resident step, 3 steps each after 1 warm-up; same blocks; chroma counts the 64x64-luma-area "
                                 "block (34x34 chroma inputs) as the unit, as the luma figure does"}
+
+        if args.precision == "f16x3":
+            out["extra"]["trained_like"] = trained_like_extra(eng, dev, n, step, timed)
 
         def classes(comp):
             """hipEvent time of every kernel class over 3 steps (events around every launch: a few % slower than the untimed step)."""
@@ -203,8 +293,13 @@ def main():
     ap.add_argument("--lib", default=None, help="path of another build of libpmp_hip.so (same-box A/B timing, tools/lib_ab.py)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the side measurements after the timed region (host-buffer end-to-end rate, chroma, per-QP luma)")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)      # internal: "<blocks>,<seed>,<threads>" (cpu_all_cores)
     args = ap.parse_args()
 
+    if args.cpu_worker:
+        b, sd, th = (int(t) for t in args.cpu_worker.split(","))
+        cpu_worker(b, sd, th)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # no launcher: become one (before any GPU call)
         raise SystemExit(launch_ranks(args.gpus))
     # stdout carries exactly ONE line, the JSON: whatever a library prints on fd 1 (gloo / RCCL banners) goes to stderr
@@ -307,11 +402,16 @@ def main():
     if dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
+    from pmp_vvc_tip2023_amd import sensors
+    sampler = sensors.Sampler(sensors.for_torch_device(local_rank))     # sysfs reads on a host thread: this GPU's clock and socket power
+    sampler.__enter__()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(timed=True)
     eng.synchronize()            # every step's range-guard snapshot looked at (and a saturated step re-run) inside the timed region
     own_elapsed = time.perf_counter() - t0
+    sampler.__exit__()
+    sens = sampler.summary()
     if dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -326,16 +426,27 @@ def main():
         elapsed = float(t.item())
         # what the collective cost and how even the ranks were: if the N-GPU number disappoints, the line says why
         g_ms = (sum(a.elapsed_time(b) for a, b in gather_events) if gather_events else gather_host_s[0] * 1e3) / max(args.steps, 1)
-        mine = torch.tensor([own_elapsed / args.steps * 1e3, g_ms], dtype=torch.float64, device="cpu" if cpu_side else dev)
+        def sv(key, stat):
+            return float(sens[key][stat]) if sens.get(key) else -1.0
+        mine = torch.tensor([own_elapsed / args.steps * 1e3, g_ms, sv("sclk_mhz", "mean"), sv("sclk_mhz", "min"), sv("power_w", "mean"),
+                             sv("power_w", "max"), float(eng.workspace_bytes())], dtype=torch.float64, device="cpu" if cpu_side else dev)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
+
+        def col(i, nd=1):
+            return [None if float(e[i].item()) < 0 else round(float(e[i].item()), nd) for e in every]
         multi = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
                  "gather_bytes_per_step": n * 1344 * world, "gather_ms": round(float(every[0][1].item()), 4),
                  "gather_ms_by_rank": [round(float(e[1].item()), 4) for e in every],
                  "ms_per_step_by_rank": [round(float(e[0].item()), 4) for e in every],
                  "preflight_ms": round(preflight["ms"], 2) if preflight else None,
+                 "sclk_mhz_mean_by_rank": col(2), "sclk_mhz_min_by_rank": col(3), "power_w_mean_by_rank": col(4), "power_w_max_by_rank": col(5),
+                 "workspace_bytes_by_rank": [int(e[6].item()) for e in every],
                  "note": "gather_ms: events around the collective on rank 0's stream (it waits for the slowest rank's records, so skew "
-                         "shows up here); ms_per_step_by_rank: each rank's own loop before the closing barrier"}
+                         "shows up here); ms_per_step_by_rank: each rank's own loop before the closing barrier; sclk / power: every rank's own "
+                         "GPU sampled from sysfs hwmon by a host thread during the timed region (pmp_vvc_tip2023_amd/sensors.py; null = not "
+                         "readable) - the dominant kernels are clock-limited under the package power cap, so a sub-linear curve with lower "
+                         "clocks than the 1-GPU line's `sensors` is node power, with even clocks and a long gather_ms it is the exchange"}
 
     blocks_per_s = n * n_gpus * args.steps / elapsed
     launches, ms, flops = kt[DOMINANT]
@@ -369,10 +480,10 @@ def main():
         t_launch = ms / launches * 1e-3
         roof["hbm_view"] = {"algorithmic_bytes_per_launch": round(alg_bytes), "achieved": round(alg_bytes / t_launch / 1e9, 1),
                             "traffic_rate": round(traffic / t_launch / 1e9, 1) if traffic else None, "peak": 8000, "unit": "GB/s",
-                            "frac": round(alg_bytes / t_launch / 8e12, 4), "copy_bandwidth_measured": 5110,
+                            "frac": round(alg_bytes / t_launch / 8e12, 4), "copy_bandwidth_from_profiles_r03_notes": 5110,
                             "note": "bytes = pixels x 64 channels x %d B x (in + out + residual on every second launch); the PMC traffic is lower "
-                                    "than that where the residual still sits in L2 / MALL; a device-to-device copy sustains 5110 GB/s on "
-                                    "this pool (tools/hbm_probe.py, profiles/r03_notes.txt section 3)" % act_bytes}
+                                    "than that where the residual still sits in L2 / MALL; a device-to-device copy sustained 5110 GB/s on "
+                                    "this pool in round 3 (tools/hbm_probe.py, profiles/r03_notes.txt section 3: a recorded figure, not re-measured by this run)" % act_bytes}
 
     if args.breakdown and rank == 0:
         eng.ktime_enable(0xFFFF)
@@ -408,6 +519,7 @@ def main():
             "blocks_per_s": round(blocks_per_s, 1),
             "net_tflops": round(blocks_per_s * FLOP_PER_BLOCK[args.comp] / 1e12, 2),
             "roofline": roof,
+            "sensors": sens,
         }
         if multi:
             out["multi_gpu"] = multi

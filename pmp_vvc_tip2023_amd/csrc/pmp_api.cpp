@@ -140,6 +140,7 @@ static int run_graph(pmp_ctx *c, F &&fwd)
 // white, 1- and 2-pixel checkerboards, stripes, step edges, white noise, and smooth random content of three grain sizes (the kind
 // recipe R makes).  Deterministic (a 64-bit LCG), so every context, rank and run derives the same exponents from the same weights.
 constexpr int PMP_CAL_BLOCKS = 32;
+constexpr int PMP_CAL_PASS = 4;             // blocks per calibration pass
 constexpr int PMP_CAL_TARGET_EXP = 12;      // a segment whose calibration maximum exceeds 2^12 is scaled down to it: 16x headroom to 65504
 
 static void make_calibration_blocks(std::vector<uint8_t> &y, std::vector<uint8_t> &u, std::vector<uint8_t> &v)
@@ -216,11 +217,19 @@ static int calibrate_mtt(pmp_ctx *c, bool luma, NetWeights &wq, NetWeights &wb)
     float *dq = (float *)(base + o_q), *dbt = (float *)(base + o_bt), *ddr = (float *)(base + o_dr);
     const int saved = c->precision;
     c->precision = PMP_PRECISION_F32;
-    c->cal_log.clear();
-    rc = run_graph(c, [&] { return forward_q(c, luma, wq, dy, du, dv, n, dq); });
-    c->cal_on = 1;
-    if (rc == PMP_OK) rc = run_graph(c, [&] { return forward_msbd(c, luma, wb, dy, du, dv, dq, n, dbt, ddr); });
-    c->cal_on = 0;
+    // passes of PMP_CAL_PASS blocks: the calibration must not be what sizes the activation workspace (a 4-block call stays in 11 MB,
+    // include/pmp.h); every pass folds into the same slots, so the log is that of the first pass
+    rc = PMP_OK;
+    for (int o = 0; o < n && rc == PMP_OK; o += PMP_CAL_PASS) {
+        const int m = std::min(PMP_CAL_PASS, n - o);
+        c->cal_log.clear();
+        rc = run_graph(c, [&] { return forward_q(c, luma, wq, dy + (size_t)o * 68 * 68, du + (size_t)o * 34 * 34, dv + (size_t)o * 34 * 34, m, dq + (size_t)o * 64); });
+        c->cal_on = 1;
+        if (rc == PMP_OK)
+            rc = run_graph(c, [&] { return forward_msbd(c, luma, wb, dy + (size_t)o * 68 * 68, du + (size_t)o * 34 * 34, dv + (size_t)o * 34 * 34, dq + (size_t)o * 64, m,
+                                                        dbt + (size_t)o * 768, ddr + (size_t)o * 768); });
+        c->cal_on = 0;
+    }
     c->precision = saved;
     if (rc != PMP_OK) return rc;
     std::vector<unsigned> bits(PMP_CAL_SLOTS);

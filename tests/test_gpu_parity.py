@@ -754,6 +754,35 @@ def test_driver_end_to_end_files(eng, oracle_lib, tmp_path):
         assert open(out / "j1" / "PartitionMat" / nm, "rb").read() == open(out2 / "j1" / "PartitionMat" / nm, "rb").read(), nm
 
 
+def test_driver_overlap_default_is_byte_identical(tmp_path):
+    """The CLI driver turns the library's overlap mode ON by default (--noOverlap turns it off): passes of >= 1024 blocks run as two chunks
+    on two streams.  A sequence large enough to be cut (2 frames of 2048x1088 = 1088 blocks per pass) gives the same files either way."""
+    import os
+    from pmp_vvc_tip2023_amd import inference_qbd as D, synth
+    inp = tmp_path / "in"; cfg = tmp_path / "cfg"
+    inp.mkdir(); cfg.mkdir()
+    w, h, fr = 2048, 1088, 2
+    with open(inp / "table.txt", "w") as f:
+        f.write("SeqO,SeqO_2048x1088_30.yuv,%d,%d,%d,30\n#end!!!!\n" % (w, h, fr))
+    y, u, v = synth.recipe_r_frames(fr, h, w, 91)
+    with open(inp / "SeqO_2048x1088_30.yuv", "wb") as f:
+        for i in range(fr):
+            f.write(y[i].tobytes()); f.write(u[i].tobytes()); f.write(v[i].tobytes())
+    with open(cfg / "SeqO.cfg", "w") as f:
+        f.write("InputFile                     : SeqO_2048x1088_30.yuv\nInputBitDepth                 : 8\n")
+    outs = {}
+    for tag, extra in (("on", []), ("off", ["--noOverlap"])):
+        out = tmp_path / ("out_" + tag)
+        D.main(["--jobID", "j", "--inputDir", str(inp), "--outDir", str(out), "--seqTable", "table.txt", "--cfgDir", str(cfg), "--ssRatio", "1",
+                "--startSeqID", "0", "--seqNum", "1", "--qps", "22,32", "--allowSyntheticMTT"] + extra)
+        d = out / "j" / "PartitionMat"
+        outs[tag] = {n: open(d / n, "rb").read() for n in sorted(os.listdir(d))}
+    assert len(outs["on"]) == 4 and list(outs["on"]) == list(outs["off"])
+    for n in outs["on"]:
+        assert outs["on"][n] == outs["off"][n], n
+        assert outs["on"][n].count(b"\n") == fr * (5 * (16 * 17) * (16 * 32) + (8 * 17) * (8 * 32))
+
+
 def test_config4_4k_frame_sharded_equals_unsharded(eng, oracle_lib):
     """BASELINE.json configs[3] on one GPU: a synthetic 3840x2160 frame (1980 blocks).  Processing the block stream in the
     contiguous shards 8 ranks would take (parallel.shard_bounds) and concatenating the records gives the same bytes as

@@ -26,8 +26,8 @@ def _clean_env(**extra):
 
 
 # ------------------------------------------------------------------------------------------------ the tail at full size
-@pytest.mark.parametrize("qp", [22, 27])
-def test_full_size_logit_tail_default_datapath_and_guard_fallback(qp):
+@pytest.mark.parametrize("comp,qp,n", [("Luma", 22, 4096), ("Luma", 27, 4096), ("Luma", 32, 1024), ("Luma", 37, 1024), ("Chroma", 22, 4096)])
+def test_full_size_logit_tail_default_datapath_and_guard_fallback(comp, qp, n):
     """4096 fresh recipe-R luma blocks (the campaign's seeds, tests/campaign_gpu.py): max |logit - oracle| < 1e-3 on the default f16x3
     datapath and on the exact fp32 MFMA datapath the range guard falls back to.  The 512-block tests sit at 1.9e-4; the tail at this
     size is 6.2e-4 / 5.6e-4 (profiles/r03_parity_campaign.txt) - Luma_Q's conditioning at low QP, the torch oracle itself is 3.3e-4
@@ -35,33 +35,36 @@ def test_full_size_logit_tail_default_datapath_and_guard_fallback(qp):
     The MAXIMUM over 4096 blocks is one sample of a chaotic tail: every change of summation order in the first layers moved it (6.2e-4,
     6.7e-4, 7.9e-4 over the builds of round 4; 7.9e-4 ... 8.7e-4 at 15 840 blocks) while the distribution stayed where it was (p99
     1.9e-4, p99.9 4.4-4.5e-4) and the HIP path stayed as close to fp64-accumulated convolutions as the oracle is
-    (profiles/r04_campaign_config4_all.txt).  The tolerance is asserted on the maximum, the trip wire on the quantiles."""
+    (profiles/r04_campaign_config4_all.txt).  The tolerance is asserted on the maximum, the trip wire on the quantiles - for BOTH datapaths
+    (round 5: the fp32 fallback is 7.6e-4 from the oracle on Luma QP27 at 15 840 blocks, profiles/r04_campaign_config4_all.txt; its old
+    6.5e-4 bound on the maximum was a sample of the same chaotic tail).  Round 5 also puts Chroma QP22 at full size and Luma QP32 / QP37 at
+    1024 blocks under the driver's eyes (the oracle costs ~75 s per 4096 luma blocks on 16 host threads; the other nets at both sizes:
+    tests/campaign_gpu.py)."""
     from oracle import nets_torch as O
     from pmp_vvc_tip2023_amd import engine, synth, weights as W
-    n = 4096
+    luma = comp == "Luma"
     torch.set_num_threads(min(16, os.cpu_count() or 1))
-    y, _, _ = synth.recipe_r_blocks(n, 5000 + qp)
-    wq, _ = W.load_net_weights("Luma_Q", qp)
-    wbd, _ = W.load_net_weights("Luma_MSBD", qp, allow_synthetic=True)
-    oq, obt, od = O.infer_qbd(wq, wbd, O.luma_input(y), True, batch=64)
+    y, u, v = synth.recipe_r_blocks(n, 5000 + qp + (0 if luma else 500))
+    wq, _ = W.load_net_weights(comp + "_Q", qp)
+    wbd, _ = W.load_net_weights(comp + "_MSBD", qp, allow_synthetic=True)
+    oq, obt, od = O.infer_qbd(wq, wbd, O.luma_input(y) if luma else O.chroma_input(y, u, v), luma, batch=64)
     e = engine.Engine(0, allow_synthetic_mtt=True)
     try:
         out = {}
         for prec in ("f16x3", "fp32"):
             e.set_precision(prec)
-            qt, bt, dire = e.inference_pre_QBD("Luma", qp, y)
+            qt, bt, dire = e.inference_pre_QBD(comp, qp, y, u, v)
             assert not e.saturated()
             per_block = np.maximum(np.abs(qt - oq).reshape(n, -1).max(1),
                                    np.maximum(np.abs(bt - obt).reshape(n, -1).max(1), np.abs(dire - od).reshape(n, -1).max(1)))
             out[prec] = per_block
-            print("\n  Luma QP%d %-5s 4096 blocks: max |logit - oracle| %.2e (margin %.2fx inside 1e-3), per block median %.1e p99 %.1e p99.9 %.1e"
-                  % (qp, prec, per_block.max(), TOL / per_block.max(), np.median(per_block), np.quantile(per_block, 0.99),
+            print("\n  %s QP%d %-5s %d blocks: max |logit - oracle| %.2e (margin %.2fx inside 1e-3), per block median %.1e p99 %.1e p99.9 %.1e"
+                  % (comp, qp, prec, n, per_block.max(), TOL / per_block.max(), np.median(per_block), np.quantile(per_block, 0.99),
                      np.quantile(per_block, 0.999)), flush=True)
         for prec, pb in out.items():
-            assert pb.max() < TOL, "Luma QP%d on %s: logits off by %g" % (qp, prec, pb.max())
-        q99, q999 = np.quantile(out["f16x3"], 0.99), np.quantile(out["f16x3"], 0.999)
-        assert q99 < 2.5e-4 and q999 < 5.5e-4, "the default datapath's tail moved: p99 %.2e, p99.9 %.2e (round 4: 1.9e-4 / 4.4e-4 at QP22)" % (q99, q999)
-        assert out["fp32"].max() < 6.5e-4, "the range guard's fallback datapath is %.2e from the oracle (round 3: 5.5e-4)" % out["fp32"].max()
+            assert pb.max() < TOL, "%s QP%d on %s: logits off by %g" % (comp, qp, prec, pb.max())
+            q99, q999 = np.quantile(pb, 0.99), np.quantile(pb, 0.999)
+            assert q99 < 2.5e-4 and q999 < 5.5e-4, "%s QP%d on %s: the tail moved: p99 %.2e, p99.9 %.2e (round 4, f16x3: 1.9e-4 / 4.4e-4 at Luma QP22)" % (comp, qp, prec, q99, q999)
     finally:
         e.close()
 

@@ -3,7 +3,7 @@ i.e. the whole-job rate including file I/O, H2D, D2H, text formatting and file w
 path only).  Prints the main thread's wall time per stage (inference_qbd.Stages), the pure-GPU time of the same passes for
 comparison, and the N-rank critical path those stages project to with sharded emission.
 
-Usage: python tools/driver_bench.py [W H FRAMES] [--emit sharded|gather] [--seqs K]      default 1920 1080 8"""
+Usage: python tools/driver_bench.py [W H FRAMES] [--emit sharded|gather] [--seqs K] [--abOverlap 1]      default 1920 1080 8"""
 import os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -93,3 +93,15 @@ for N in (2, 4, 8):
     else:                          # rank 0 formats and writes everything: only the passes shrink
         crit = st.t["gpu_wait"] / N + (dt - st.t["gpu_wait"])
     print("  projected critical path at %d ranks: %.3f s  (x%.2f)%s" % (N, crit, dt / crit, "  [weight loading is the longer leg]" if emit_mode == "sharded" and hidden > rows / N else ""))
+
+# --abOverlap 1: the driver's default (overlap mode on) against --noOverlap, alternating, same process and box (round 5)
+if opt.get("--abOverlap") == "1":
+    res = {"on": [], "off": []}
+    for rep in range(4):
+        for tag, extra in (("on", []), ("off", ["--noOverlap"])):
+            t1 = time.time()
+            D.main(args + extra)
+            res[tag].append(time.time() - t1)
+    on, off = min(res["on"]), min(res["off"])
+    print("  overlap A/B, whole job (best of 4, alternating): on %.3f s, off %.3f s -> %+.2f %%  (all runs on: %s | off: %s)"
+          % (on, off, 100 * (on - off) / off, " ".join("%.3f" % t for t in res["on"]), " ".join("%.3f" % t for t in res["off"])))
