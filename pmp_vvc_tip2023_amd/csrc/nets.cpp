@@ -162,6 +162,7 @@ struct Graph {
             if (consume) release(x_in);
             return y;
         }
+        if (!gate && consume && fused32(x_in, r) && (pool ? out_f32 : !out_f32) && (!pool || r.cout_pad == 16)) return rb_fused32(x_in, name, r, pool);
         Act x = to_conv_input(x_in);
         const bool converted = x.p != x_in.p || x.off != x_in.off;
         if (converted && consume) release(x_in);
@@ -198,6 +199,31 @@ struct Graph {
         check(launch_stem(c->stream, luma, msbd, a), "stem");
         note(o, "stem", seg);
         return o;
+    }
+
+    // rbfuse32.hip (f16x3): a ResidualBlock with <= 32 output channels at 32x32 as ONE launch, the intermediate in LDS; bit-identical to rb().
+    // pool_f32: + 2x2 max-pool, plain fp32 output (trunk_B3.2, read by the head kernel).
+    bool fused32(const Act &x, const RBWeights &r) const
+    {
+        return h2() && c->fuse32 && x.H == 32 && x.W == 32 && x.split && r.w0h && r.has_sc && !r.direct && r.k == 3 &&
+               ((r.cin_pad == 32 && r.cout_pad == 16) || (r.cin_pad == 16 && r.cout_pad == 16) || (r.cin_pad == 16 && r.cout_pad == 32));
+    }
+    Act rb_fused32(Act &x, const std::string &name, const RBWeights &r, bool pool_f32)
+    {
+        const int H = x.H, W = x.W;
+        Act y = alloc(r.cout, pool_f32 ? H / 2 : H, pool_f32 ? W / 2 : W, !pool_f32);
+        if (live()) {
+            RbFuse32Args a{};
+            a.x = x.s(); a.x_stride = x.stride;
+            a.w0 = r.w0h; a.w2 = r.w2h; a.wsc = r.wsch; a.s0 = std::ldexp(1.f, -r.k0); a.s2 = std::ldexp(1.f, -r.k2);
+            if (pool_f32) a.out_f32 = y.p; else { a.out = y.s(); a.out_stride = y.stride; }
+            a.sat = sat(); a.N = n; a.H = H; a.W = W; a.cin_groups = r.cin_pad / 16; a.cout_groups = r.cout_pad / 16; a.pool_f32 = pool_f32 ? 1 : 0;
+            const double px = (double)n * H * W;
+            KScope ks(c, K_CONV_OTHER, 2.0 * px * r.cout * (r.cin * 9 + r.cout * 9 + r.cin));
+            check(launch_rbfuse32(c->stream, a), "rbfuse32");
+        }
+        release(x);
+        return y;
     }
 
     // chain16.hip: f16x3 only, and only with every block it names loaded in that format

@@ -888,7 +888,9 @@ int pmp_debug_set_fusion(pmp_ctx *c, int on)
     CHECK_CTX(c);
     const int rc = settle(c);
     if (rc != PMP_OK) return rc;
-    c->fuse16 = on ? 1 : 0;
+    if (on < 0 || on > 3) return set_err(c, PMP_E_INVALID, "pmp_debug_set_fusion: 0 (none), 1 (all), 2 (16x16 tails only), 3 (32x32 ResidualBlocks only)");
+    c->fuse16 = (on == 1 || on == 2) ? 1 : 0;
+    c->fuse32 = (on == 1 || on == 3) ? 1 : 0;
     return PMP_OK;
 }
 

@@ -82,6 +82,21 @@ struct Chain16QtArgs {
 };
 hipError_t launch_qt_tail16(hipStream_t s, const Chain16QtArgs &a);
 
+// ------------------------------------------------------------------------------------------------ a ResidualBlock at 32x32, one launch
+// rbfuse32.hip (f16x3 datapath): conv3x3 + ReLU, conv3x3 + 1x1 shortcut + ReLU [+ 2x2 max-pool] of a block with <= 32 output channels,
+// the intermediate resident in LDS; bit-identical to two launches of conv_f16x3.hip.  Shapes: (cin_groups, cout_groups, pool_f32) =
+// (2, 1, 0) trunk_B3.1, (1, 1, 1) trunk_B3.2, (1, 2, 0) trunk_Att2.0.
+struct RbFuse32Args {
+    const unsigned short *x; size_t x_stride;        // [N][cin_groups][H][W][16] split-2
+    const unsigned short *w0, *w2, *wsc;             // the block's pack_h2 streams (RBWeights::w0h / w2h / wsch)
+    float s0, s2;                                    // 1/S of the two passes
+    unsigned short *out; size_t out_stride;          // [N][cout_groups][H][W][16] split-2 ...
+    float *out_f32;                                  // ... or, with pool_f32, [N][cout_groups][H/2][W/2][16] plain fp32
+    unsigned *sat;
+    int N, H, W, cin_groups, cout_groups, pool_f32;
+};
+hipError_t launch_rbfuse32(hipStream_t s, const RbFuse32Args &a);
+
 // ------------------------------------------------------------------------------------------------ stems
 // First layers straight from the u8 blocks (Model_QBD.py:79-80, :130-135, :177-178, :228-233).
 // luma: block_y u8[N][68][68];  chroma: + block_u/v u8[N][34][34], plane 0 = 2x2 max-pool of block_y

@@ -78,8 +78,9 @@ class Engine:
         self._ck(self.lib.pmp_set_precision(self.h, {"fp32": 0, "f32": 0, "bf16x6": 1, "f16x3": 2}[mode]))
 
     def set_fusion(self, on):
-        """f16x3: the 16x16-resolution tails as one launch per net (default) or launch per layer - bit-identical results (include/pmp.h)."""
-        self._ck(self.lib.pmp_debug_set_fusion(self.h, 1 if on else 0))
+        """f16x3 launch fusion (include/pmp.h: pmp_debug_set_fusion; bit-identical results either way): True / 1 = all (default), False / 0 =
+        launch per layer, 2 = only the 16x16 tails (chain16.hip), 3 = only the 32x32 ResidualBlocks (rbfuse32.hip)."""
+        self._ck(self.lib.pmp_debug_set_fusion(self.h, int(on)))
 
     def get_precision(self):
         return {0: "fp32", 1: "bf16x6", 2: "f16x3"}[self.lib.pmp_get_precision(self.h)]

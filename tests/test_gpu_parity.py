@@ -523,6 +523,11 @@ def test_fused_16x16_tails_are_bit_identical(comp):
             for nm, p, q in zip(("qt", "bt", "dire"), a, b):
                 assert np.array_equal(p, q), "%s QP%d %s: fused and per-layer paths differ by %g" % (comp, qp, nm, np.abs(p - q).max())
             assert np.isfinite(a[0]).all() and np.abs(a[1]).max() > 0.1      # not a comparison of two empty results
+            for mode in (2, 3):      # each family of fused kernels alone: the 16x16 tails (chain16.hip), the 32x32 ResidualBlocks (rbfuse32.hip)
+                e.set_fusion(mode)
+                m = e.inference_pre_QBD(comp, qp, y, u, v)
+                for nm, p, q in zip(("qt", "bt", "dire"), m, b):
+                    assert np.array_equal(p, q), "%s QP%d %s: fusion mode %d and the per-layer path differ by %g" % (comp, qp, nm, mode, np.abs(p - q).max())
         e.set_fusion(True)
         e.set_chunk(37)
         try:
@@ -539,7 +544,7 @@ def test_fused_16x16_tails_are_bit_identical(comp):
             e.inference_pre_QBD(comp, 22, y[:8], u[:8], v[:8])
             counts[on] = sum(int(ln) for ln, _, _ in e.ktime().values())
             e.ktime_enable(0)
-        assert counts[False] - counts[True] >= 25 and counts[True] <= 45, counts      # 67 -> 40 launches per (QT + MTT) pass
+        assert counts[False] - counts[True] >= 28 and counts[True] <= 42, counts      # 67 -> 37 launches per (QT + MTT) pass
         assert len(names) >= 6
         if comp == "Luma":          # range stress: the clamp fires inside the fused kernels too - same clamped bits, same raised flag
             e.load("Luma", 22)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Same-box, same-process A/B of the fused 16x16 tails (chain16.hip) against the launch-per-layer path: interleaved rounds of the
-device-resident step (pmp_infer_postprocess_records_device), luma and chroma, 4096 blocks.  Prints ms per step per arm and round, the
-median, and the per-class kernel times of one step per arm.   python tools/fusion_ab.py [rounds] [steps]"""
+"""Same-box, same-process A/B of the launch fusions (pmp_debug_set_fusion: 1 = all, 2 = 16x16 tails only (chain16.hip), 3 = 32x32 ResidualBlocks
+only (rbfuse32.hip), 0 = launch per layer): interleaved rounds of the device-resident step (pmp_infer_postprocess_records_device), luma and
+chroma, 4096 blocks.  Prints ms per step per arm and round, the median, and the per-class kernel times of one step per arm.
+    python tools/fusion_ab.py [rounds] [steps]"""
 import os
 import sys
 import time
@@ -30,29 +31,31 @@ def main():
             for _ in range(k):
                 e.infer_postprocess_records_device(comp, 22, d[0].data_ptr(), pu, pv, n, rec.data_ptr())
             e.synchronize()
-        ms = {True: [], False: []}
+        ARMS = (1, 2, 3, 0)
+        NAME = {1: "all fused", 2: "tails only", 3: "rb32 only", 0: "per-layer"}
+        ms = {a: [] for a in ARMS}
         ref = {}
-        for on in (True, False):
+        for on in ARMS:
             e.set_fusion(on)
             run(2)
             ref[on] = rec.clone()
-        assert torch.equal(ref[True], ref[False]), "records differ between the fused and the per-layer path"
+        assert all(torch.equal(ref[a], ref[0]) for a in ARMS), "records differ between the fused and the per-layer path"
         for r in range(rounds):
-            for on in (True, False):
+            for on in ARMS:
                 e.set_fusion(on)
                 run(1)
                 t = time.perf_counter()
                 run(steps)
                 ms[on].append((time.perf_counter() - t) / steps * 1e3)
-        for on in (True, False):
-            print("%-6s %-10s ms/step per round: %s   median %.3f" % (comp, "fused" if on else "per-layer", " ".join("%.3f" % x for x in ms[on]), float(np.median(ms[on]))), flush=True)
-        for on in (True, False):
+        for on in ARMS:
+            print("%-6s %-10s ms/step per round: %s   median %.3f" % (comp, NAME[on], " ".join("%.3f" % x for x in ms[on]), float(np.median(ms[on]))), flush=True)
+        for on in ARMS:
             e.set_fusion(on)
             e.ktime_enable(0xFFFF)
             run(1)
             kt = e.ktime()
             e.ktime_enable(0)
-            print("   %-10s %s | launches %d" % ("fused" if on else "per-layer", "  ".join("%s %.3f ms" % (k.replace("conv_mfma_", ""), v[1]) for k, v in kt.items()),
+            print("   %-10s %s | launches %d" % (NAME[on], "  ".join("%s %.3f ms" % (k.replace("conv_mfma_", ""), v[1]) for k, v in kt.items()),
                                                sum(v[0] for v in kt.values())), flush=True)
     e.close()
 
