@@ -275,6 +275,10 @@ int pmp_debug_set_fusion(pmp_ctx *ctx, int on);
  *      buf (may be NULL): one text line per recorded tensor, "<name> <segment> <max |value|>\n", in launch order ("<block>.t" is the
  *      intermediate of a ResidualBlock).  Returns the number of recorded tensors or a negative error. ---- */
 int pmp_debug_activation_report(pmp_ctx *ctx, int comp, int qp, int exps[5], float seg_amax[5], char *buf, int64_t cap);
+/* ---- test hook: on = 0 runs the f16x3 datapath with exponents of zero whatever the calibration chose (how the range-guard tests still
+ *      drive activations out of the fp16 range: with the scales on, their power-of-two stress weights simply get larger exponents);
+ *      on = 1 (default) uses the calibrated exponents.  Settles the calls in flight first. ---- */
+int pmp_debug_set_activation_scales(pmp_ctx *ctx, int on);
 
 /* ---- test hook (host only, no GPU needed): the f16x3 weight packing of one OIHW conv tensor (conv_f16x3.hip).
  *      Writes the power-of-two exponent k of the scale S = 2^k to *scale_exp and, if out != NULL, the packed stream

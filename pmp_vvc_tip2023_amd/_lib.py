@@ -71,6 +71,7 @@ SIGNATURES = {
     "pmp_debug_set_conv_variant": (_I, [_I]),
     "pmp_debug_set_winograd": (_I, [_VP, _I]),
     "pmp_debug_set_fusion": (_I, [_VP, _I]),
+    "pmp_debug_set_activation_scales": (_I, [_VP, _I]),
     "pmp_debug_activation_report": (_I, [_VP, _I, _I, C.POINTER(_I), C.POINTER(C.c_float), C.c_char_p, _I64]),
     "pmp_debug_pack_f16x3": (C.c_int64, [C.POINTER(C.c_float), _I, _I, _I, C.POINTER(C.c_uint16), C.c_int64, C.POINTER(C.c_int)]),
     "pmp_debug_conv_bench": (_I, [_VP, _I, _I, _I, _I, _I, _I, _I] + [C.POINTER(C.c_double)] * 4),

@@ -40,7 +40,8 @@ struct Graph {
     unsigned *sat() const { return h2() ? c->d_sat : nullptr; }   // f16x3: the context's sticky saturation flag
     // f16x3 activation scales (pmp_host.h: NetWeights::act_exp): the segment the graph is in, and the exponent a segment's tensors carry
     int seg = 0;
-    int E(int sg) const { return h2() ? w.act_exp[sg] : 0; }
+    bool scaled() const { return h2() && c->act_scales && w.stem_b_h; }
+    int E(int sg) const { return scaled() ? w.act_exp[sg] : 0; }
     // calibration pass (fp32 datapath, pmp_api.cpp: calibrate_mtt): the largest |value| of a tensor just produced, per launch
     void note(const Act &a, const std::string &name, int sg)
     {
@@ -191,7 +192,7 @@ struct Graph {
         if (!live()) return o;
         // f16x3 MTT stems write segment 0 at its activation scale: 2^-e0 on the output scale and on the biases (stem_b_h)
         const int e0 = msbd ? E(0) : 0;
-        StemArgs a{by, bu, bv, q, w.stem_w, (h2() && msbd && w.stem_b_h) ? w.stem_b_h : w.stem_b, o.split ? nullptr : o.p, n, o.split ? o.s() : nullptr, o.stride, fmt(),
+        StemArgs a{by, bu, bv, q, w.stem_w, (msbd && scaled()) ? w.stem_b_h : w.stem_b, o.split ? nullptr : o.p, n, o.split ? o.s() : nullptr, o.stride, fmt(),
                    h2() ? w.stem_wh : nullptr, std::ldexp(1.f, -w.stem_k - e0), sat()};
         const int cin = (luma ? 1 : 3) + (msbd ? 1 : 0), k1 = luma ? 9 : 5, k2 = luma ? 5 : 3;
         const double macs = msbd ? (double)cin * (k1 * k1 * 16 + 2 * k1 * k2 * 8) : (double)cin * k1 * k1 * 32;
@@ -239,7 +240,7 @@ struct Graph {
     }
 
     // f16x3 MTT heads read a tensor that carries its segment's activation scale: their weights hold the way back (head_w_h = head_w * 2^e)
-    const float *head_weights(int slot, int layer) const { return (h2() && layer >= 0 && w.head_w_h[slot]) ? w.head_w_h[slot] : w.head_w[slot]; }
+    const float *head_weights(int slot, int layer) const { return (layer >= 0 && scaled()) ? w.head_w_h[slot] : w.head_w[slot]; }
 
     void head(const Act &x, int slot, int layer, float *qt, float *bt, float *dire)
     {

@@ -894,6 +894,15 @@ int pmp_debug_set_fusion(pmp_ctx *c, int on)
     return PMP_OK;
 }
 
+int pmp_debug_set_activation_scales(pmp_ctx *c, int on)
+{
+    CHECK_CTX(c);
+    const int rc = settle(c);
+    if (rc != PMP_OK) return rc;
+    c->act_scales = on ? 1 : 0;
+    return PMP_OK;
+}
+
 int pmp_debug_activation_report(pmp_ctx *c, int comp, int qp, int exps[5], float seg_amax[5], char *buf, int64_t cap)
 {
     CHECK_CTX(c);

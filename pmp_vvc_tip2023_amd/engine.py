@@ -100,6 +100,10 @@ class Engine:
     def clear_saturation(self):
         self._ck(self.lib.pmp_clear_saturation(self.h))
 
+    def set_activation_scales(self, on):
+        """f16x3: use the calibrated activation scales of the MTT nets (default) or exponents of zero (include/pmp.h; the range-guard tests)."""
+        self._ck(self.lib.pmp_debug_set_activation_scales(self.h, 1 if on else 0))
+
     def activation_report(self, comp, qp):
         """f16x3 activation scales of the MTT net of (comp, qp) and the calibration record behind them (include/pmp.h):
         {"exps": [e0..e4], "seg_amax": [..5..], "tensors": [(name, segment, max |value|), ...]}.  Loads the pair if necessary."""

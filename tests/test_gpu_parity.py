@@ -245,6 +245,7 @@ def test_overlap_mode_is_bit_identical(g1):
         yy = np.ascontiguousarray(np.concatenate([g1["block_y"]] * 70)[:1100])
         e.load("Luma", 22)
         e.load_pretrain_model("Luma_MSBD", 22, w)
+        e.set_activation_scales(False)                           # with the calibrated scales these weights stay inside fp16 (test_f16x3_range_guard)
         e.set_overlap(False)
         q0, b0, d0 = e.inference_pre_QBD("Luma", 22, yy)
         r0 = e.saturation_reruns()
@@ -331,6 +332,13 @@ def test_f16x3_range_guard(g1):
         e2.load("Luma", 22)                                    # real QT net; MTT net replaced below
         assert not e2.saturated() and e2.saturation_reruns() == 0
         e2.load_pretrain_model("Luma_MSBD", 22, w)
+        # (o) round 5: with the activation scales the calibration pass chooses (include/pmp.h) these weights - a power-of-two stress - no longer
+        # leave the fp16 range at all: right logits on the default datapath, no flag, no re-run
+        qs, bs, ds = e2.inference_pre_QBD("Luma", 22, y)
+        assert not e2.saturated() and e2.saturation_reruns() == 0
+        assert max(np.abs(qs - oq).max(), np.abs(bs - obt).max(), np.abs(ds - odire).max()) < TOL
+        assert e2.activation_report("Luma", 22)["exps"][0] >= 5           # trunk activations of 2e5..5e5 against the 4096 target
+        e2.set_activation_scales(False)                         # the guard itself, from here on: exponents of zero
         qt, bt, dire = e2.inference_pre_QBD("Luma", 22, y)     # default policy: re-run on fp32 MFMA
         assert e2.saturated() and e2.saturation_reruns() == 1
         err = max(np.abs(qt - oq).max(), np.abs(bt - obt).max(), np.abs(dire - odire).max())
@@ -378,6 +386,7 @@ def test_device_calls_do_not_stall_the_host_and_the_guard_still_repairs(g1, orac
     e2 = engine.Engine(0, allow_synthetic_mtt=True)
     try:
         e2.set_precision("f16x3")
+        e2.set_activation_scales(False)                           # the stress weights below must saturate: exponents of zero (include/pmp.h)
         e2.load("Luma", 22)
         e2.load("Luma", 27)
         # ---- (i) no host stall
@@ -550,6 +559,7 @@ def test_fused_16x16_tails_are_bit_identical(comp):
             e.load("Luma", 22)
             e.load_pretrain_model("Luma_MSBD", 22, _range_stress_weights())
             e.set_saturation_policy("ignore")
+            e.set_activation_scales(False)                       # exponents of zero: the stress weights saturate
             got = {}
             for on in (True, False):
                 e.set_fusion(on)
