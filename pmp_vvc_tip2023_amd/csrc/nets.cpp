@@ -209,6 +209,26 @@ struct Graph {
         return h2() && c->fuse32 && x.H == 32 && x.W == 32 && x.split && r.w0h && r.has_sc && !r.direct && r.k == 3 &&
                ((r.cin_pad == 32 && r.cout_pad == 16) || (r.cin_pad == 16 && r.cout_pad == 16) || (r.cin_pad == 16 && r.cout_pad == 32));
     }
+    // trunk_Att2.0 with its input built from the logits inside the kernel (no att_input launch, no input tensor)
+    Act rb_fused32_att(const std::string &name, const float *q, const float *bt, const float *dire, int layer, int S)
+    {
+        const RBWeights &r = w.rb.find(name)->second;
+        Act y = alloc(r.cout, S, S, true);
+        if (live()) {
+            RbFuse32Args a{};
+            a.w0 = r.w0h; a.w2 = r.w2h; a.wsc = r.wsch; a.s0 = std::ldexp(1.f, -r.k0); a.s2 = std::ldexp(1.f, -r.k2);
+            a.out = y.s(); a.out_stride = y.stride; a.sat = sat(); a.N = n; a.H = S; a.W = S; a.cin_groups = 1; a.cout_groups = 2;
+            a.q = q; a.bt = bt; a.dire = dire; a.att_layer = layer;
+            KScope ks(c, K_CONV_OTHER, 2.0 * n * S * S * r.cout * (r.cin * 9 + r.cout * 9 + r.cin));
+            check(launch_rbfuse32(c->stream, a), "rbfuse32(att)");
+        }
+        return y;
+    }
+    bool fused32_att(const std::string &name) const
+    {
+        auto it = w.rb.find(name);
+        return h2() && c->fuse32 && it != w.rb.end() && it->second.w0h && it->second.has_sc && it->second.cin_pad == 16 && it->second.cout_pad == 32;
+    }
     Act rb_fused32(Act &x, const std::string &name, const RBWeights &r, bool pool_f32)
     {
         const int H = x.H, W = x.W;
@@ -348,13 +368,18 @@ int forward_msbd(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, 
     }
     // attention 2 gates x4 at 32x32 (:147-150), branch B3 -> pool -> out2 (:151-153)
     g.seg = 3;
-    Act aj = g.alloc(16, 32, 32, g.x6());
-    if (g.live()) {
-        KScope ks(c, K_SMALL, 0.0);
-        g.check(launch_att_input(c->stream, qt, bt, dire, 1, aj.split ? nullptr : aj.p, n, 32, aj.split ? aj.s() : nullptr, aj.stride, g.fmt(), g.sat()), "att_input");
+    Act a2{};
+    if (g.fused32_att("trunk_Att2.0")) {
+        a2 = g.rb_fused32_att("trunk_Att2.0", qt, bt, dire, 1, 32);
+    } else {
+        Act aj = g.alloc(16, 32, 32, g.x6());
+        if (g.live()) {
+            KScope ks(c, K_SMALL, 0.0);
+            g.check(launch_att_input(c->stream, qt, bt, dire, 1, aj.split ? nullptr : aj.p, n, 32, aj.split ? aj.s() : nullptr, aj.stride, g.fmt(), g.sat()), "att_input");
+        }
+        g.note(aj, "att_input2", 3);
+        a2 = g.rb(aj, "trunk_Att2.0");
     }
-    g.note(aj, "att_input2", 3);
-    Act a2 = g.rb(aj, "trunk_Att2.0");
     Act xb3 = g.rb(a2, "trunk_Att2.1", false, &x4);
     g.release(x4);
     g.seg = 4;

@@ -94,6 +94,9 @@ struct RbFuse32Args {
     float *out_f32;                                  // ... or, with pool_f32, [N][cout_groups][H/2][W/2][16] plain fp32
     unsigned *sat;
     int N, H, W, cin_groups, cout_groups, pool_f32;
+    // x == nullptr (trunk_Att2.0 only): the block's input is the attention input cat[up(q), up(bt[att_layer]), up(dire[att_layer])], built in
+    // the kernel from the logits q [N][64], bt / dire [N][3][256] (launch_att_input's arithmetic)
+    const float *q, *bt, *dire; int att_layer;
 };
 hipError_t launch_rbfuse32(hipStream_t s, const RbFuse32Args &a);
 

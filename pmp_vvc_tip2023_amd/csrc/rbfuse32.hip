@@ -11,7 +11,7 @@
 //   out = relu((conv3x3(t) + conv1x1(in)) / S2) [2x2 max-pool]                                         -> global (split-2 planes | pooled fp32)
 //
 // Traffic per block and ResidualBlock: 1.56 x input + output instead of 2 x input + 2 x intermediate + output (B3.1: 270 KB for 457,
-// B3.2: 118 for 276, Att2.0: 233 for 523).  BIT-IDENTICAL to the launch-per-layer path (tests/test_gpu_parity.py): the same pack_h2 weight
+// B3.2: 118 for 276, Att2.0: 131 for 588 - its input, three channels made of logits, is built in the kernel and never exists in HBM).  BIT-IDENTICAL to the launch-per-layer path (tests/test_gpu_parity.py): the same pack_h2 weight
 // streams in the same K-step order (chain16_dev.h's list, restated for these image widths), the same three products per K-step into the
 // same fp32 accumulators (x0*w1, x0*w0, x1*w0), the main pass before the shortcut pass, the epilogue arithmetic of conv_f16x3.hip
 // (x 1/S, ReLU, range-flag maximum, pool, two-term split with the clamp).  A value of t that two tiles both compute is the same number
@@ -113,10 +113,14 @@ struct RbFuse32Dev {
     float *out_f32;
     unsigned *sat;
     int H, W;
+    const float *q, *bt, *dire;       // ATT: the attention trunk's input is built here, from the logits (conv_misc.hip: att_input_kernel)
+    int layer;
 };
 
 // CB_IN input groups, NT output groups (= groups of the intermediate), POOLF: 2x2 max-pool and plain fp32 output (trunk_B3.2)
-template <int CB_IN, int NT, bool POOLF>
+// ATT (trunk_Att2.0): no input tensor at all - cat[up(q), up(bt[layer]), up(dire[layer])] (Model_QBD.py:147), three channels of a 16-channel
+// group, is computed from the logits into the halo image, with att_input_kernel's arithmetic (two-term split, clamp, range flag).
+template <int CB_IN, int NT, bool POOLF, bool ATT = false>
 __global__ __launch_bounds__(512, 4) void rbfuse32_kernel(RbFuse32Dev a)
 {
     __shared__ __attribute__((aligned(16))) char img[CB_IN * RF_ISLOT];
@@ -128,8 +132,30 @@ __global__ __launch_bounds__(512, 4) void rbfuse32_kernel(RbFuse32Dev a)
     const int n = bid / tiles, t = bid - n * tiles, ty = t / tiles_x, tx = t - ty * tiles_x;
     const int H = a.H, W = a.W;
 
+    float amax = 0.f;
     // ---- input tile -> LDS halo images (zero outside the map)
-    {
+    if (ATT) {
+        static_assert(!ATT || CB_IN == 1, "the attention input is one channel group");
+        if (tid < RF_IW * RF_IW) {
+            const int row = tid / RF_IW, col = tid - row * RF_IW, gy = ty * 16 - 2 + row, gx = tx * 16 - 2 + col;
+            const int sq = H / 8, sh = H / 16;
+            u32x4 lo = {0u, 0u, 0u, 0u}, hi = {0u, 0u, 0u, 0u};
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                const size_t o = ((size_t)n * 3 + a.layer) * 256 + (gy / sh) * 16 + (gx / sh);
+                const f32x4 v = {a.q[(size_t)n * 64 + (gy / sq) * 8 + (gx / sq)], a.bt[o], a.dire[o], 0.f};
+                amax = sat_amax4(amax, v);
+                unsigned p0, q0, p1, q1;
+                h2_split_pair(v.x, v.y, p0, q0);
+                h2_split_pair(v.z, v.w, p1, q1);
+                lo.x = p0; lo.y = p1; hi.x = q0; hi.y = q1;
+            }
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4 *>(img + tid * 32) = lo;
+            *reinterpret_cast<u32x4 *>(img + tid * 32 + 16) = z;
+            *reinterpret_cast<u32x4 *>(img + RF_IPLN + tid * 32) = hi;
+            *reinterpret_cast<u32x4 *>(img + RF_IPLN + tid * 32 + 16) = z;
+        }
+    } else {
         constexpr int PIECES = CB_IN * 2 * RF_IW * RF_IW * 2, NLD = (PIECES + 511) / 512;
         u32x4 r[NLD];
 #pragma unroll
@@ -154,7 +180,6 @@ __global__ __launch_bounds__(512, 4) void rbfuse32_kernel(RbFuse32Dev a)
     }
     __syncthreads();
 
-    float amax = 0.f;
     const int ct = wave % NT, wsub = wave / NT;
     constexpr int WPG = 8 / NT;                                   // waves per output group
     // ---- first convolution on the 18x18 region: wave (ct, wsub) takes the columns-of-16 wsub, wsub + WPG, ...
@@ -253,8 +278,13 @@ __global__ __launch_bounds__(512, 4) void rbfuse32_kernel(RbFuse32Dev a)
 hipError_t launch_rbfuse32(hipStream_t s, const RbFuse32Args &h)
 {
     if ((h.H & 15) || (h.W & 15) || h.N <= 0) return hipErrorInvalidValue;
-    RbFuse32Dev a{h.x, h.x_stride, h.w0, h.w2, h.wsc, h.s0, h.s2, h.out, h.out_stride, h.out_f32, h.sat, h.H, h.W};
+    RbFuse32Dev a{h.x, h.x_stride, h.w0, h.w2, h.wsc, h.s0, h.s2, h.out, h.out_stride, h.out_f32, h.sat, h.H, h.W, h.q, h.bt, h.dire, h.att_layer};
     const unsigned grid = (unsigned)h.N * (unsigned)((h.H >> 4) * (h.W >> 4));
+    if (!h.x) {
+        if (!h.q || !h.bt || !h.dire || h.cin_groups != 1 || h.cout_groups != 2 || h.pool_f32) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((rbfuse32_kernel<1, 2, false, true>), dim3(grid), dim3(512), 0, s, a);
+        return hipGetLastError();
+    }
     if (h.cin_groups == 2 && h.cout_groups == 1 && !h.pool_f32) hipLaunchKernelGGL((rbfuse32_kernel<2, 1, false>), dim3(grid), dim3(512), 0, s, a);
     else if (h.cin_groups == 1 && h.cout_groups == 1 && h.pool_f32) hipLaunchKernelGGL((rbfuse32_kernel<1, 1, true>), dim3(grid), dim3(512), 0, s, a);
     else if (h.cin_groups == 1 && h.cout_groups == 2 && !h.pool_f32) hipLaunchKernelGGL((rbfuse32_kernel<1, 2, false>), dim3(grid), dim3(512), 0, s, a);
