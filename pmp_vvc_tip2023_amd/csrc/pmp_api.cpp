@@ -264,7 +264,7 @@ static int infer_passes(pmp_ctx *c, bool luma, NetWeights &wq, NetWeights &wb, c
     int rc0;     // weights are packed per datapath, on first use (the load packed the datapath that was current then)
     if ((rc0 = ensure_datapath(c, wq, c->precision)) != PMP_OK || (rc0 = ensure_datapath(c, wb, c->precision)) != PMP_OK) return rc0;
     // f16x3: the MTT net's activation scales, from one calibration pass when the net is first used on this datapath
-    if (c->precision == PMP_PRECISION_F16X3 && !wb.calibrated && (rc0 = calibrate_mtt(c, luma, wq, wb)) != PMP_OK) return rc0;
+    if (c->precision == PMP_PRECISION_F16X3 && c->act_scales && !wb.calibrated && (rc0 = calibrate_mtt(c, luma, wq, wb)) != PMP_OK) return rc0;
     if ((rc0 = abl_prepare_pass(c, wq, wb)) != PMP_OK) return rc0;
     // Overlap mode: a call of at least 1024 blocks runs as (at least) two chunks, even ones on the context's stream and workspace, odd
     // ones on a second stream with a second workspace, so that one chunk's small launches (stems, 16x16 tails, HBM-bound 32x32 layers)
