@@ -56,42 +56,38 @@ struct RfSteps {
     static constexpr int D = NS < 2 ? NS : 2;               // K-steps of weight lead
 };
 
-// One pass over CB source groups into KI accumulators of this wave (KI pixel columns-of-16 x ONE output group `ct` of NT).  pb[k]: this
-// lane's byte offset of item k's window origin inside a group plane (+ 16 for the upper 8 channels); the LAST item is skipped unless
-// `last` (wave-uniform: the 21 columns-of-16 of the first convolution do not divide evenly among the waves).  Order per accumulator: x0*w1, x0*w0, x1*w0, K-step after K-step - the launch path's.
-template <int T, int CB, int NT, int KI, int IMW, int SLOT, int PLN>
-__device__ __forceinline__ void rf_accumulate(const char *src, const unsigned short *wpk, int lane, int ct, const int (&pb)[KI], bool last, f32x4 (&acc)[KI])
+// One pass over CB source groups into KI accumulators of this wave (KI pixel columns-of-16 x ONE output group).  Item k's window origin
+// for this lane: pb[k] bytes inside a group plane (+ 16 for the upper 8 channels) if ISTR == 0, else pb[0] + k * ISTR (consecutive rows:
+// the offsets become instruction immediates).  The LAST item is skipped unless `last` (wave-uniform: the 21 columns-of-16 of the first
+// convolution do not divide evenly among the waves).  wbase: the pass's weight stream at this wave's output group (uniform), wv: lane * 16.
+// Order per accumulator: x0*w1, x0*w0, x1*w0, K-step after K-step - the launch path's.
+template <int T, int CB, int NT, int KI, int IMW, int SLOT, int PLN, int ISTR, int NPB>
+__device__ __forceinline__ void rf_accumulate(const char *src, const char *wbase, unsigned wv, bool hi, const int (&pb)[NPB], bool last, f32x4 (&acc)[KI])
 {
     typedef RfSteps<T, CB> ST;
-    constexpr int NS = ST::NS, D = ST::D;
-    const int g = lane >> 4;
-    const bool hi = (g >> 1) != 0;
-    const RF_GLOBAL f16x8 *wl = (const RF_GLOBAL f16x8 *)wpk + lane + ct * 64;
+    constexpr int NS = ST::NS, D = ST::D, WSTEP = 2 * NT * 64 * 16;      // bytes of weight stream per K-step
+    auto wld = [&](int st, int sp) __attribute__((always_inline)) {
+        return *reinterpret_cast<const RF_GLOBAL f16x8 *>((const RF_GLOBAL char *)wbase + (st * WSTEP + sp * (NT * 64 * 16)) + wv);
+    };
     f16x8 wq[D][2];
 #pragma unroll
-    for (int st = 0; st < D; ++st) { wq[st][0] = wl[(size_t)st * (2 * NT * 64)]; wq[st][1] = wl[(size_t)st * (2 * NT * 64) + NT * 64]; }
-    constexpr bool DB = false && KI <= 3;                             // pixel fragments of the next K-step on their way during this one's MFMAs (registers permitting)
-    f16x8 xq[DB ? 2 : 1][2][KI];
-    auto xload = [&](int st) __attribute__((always_inline)) {
+    for (int st = 0; st < D; ++st) { wq[st][0] = wld(st, 0); wq[st][1] = wld(st, 1); }
+    f16x8 xa[KI], xb[KI];
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
         int off = hi ? rf_step_off<T, CB, IMW, SLOT>(st, 1) : rf_step_off<T, CB, IMW, SLOT>(st, 0);
-        asm volatile("" : "+v"(off));      // opaque: keeps hipcc from hoisting the addresses of every K-step and item out of the pass (54 live registers)
+        asm volatile("" : "+v"(off));      // opaque: keeps hipcc from hoisting the addresses of every K-step and item out of the pass
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < KI; ++k) {
             if (k < KI - 1 || last) {
-                xq[DB ? st & 1 : 0][0][k] = *reinterpret_cast<const f16x8 *>(src + pb[k] + off);
-                xq[DB ? st & 1 : 0][1][k] = *reinterpret_cast<const f16x8 *>(src + pb[k] + off + PLN);
+                const char *p = src + (ISTR ? pb[0] + k * ISTR : pb[ISTR ? 0 : k]) + off;
+                xa[k] = *reinterpret_cast<const f16x8 *>(p);
+                xb[k] = *reinterpret_cast<const f16x8 *>(p + PLN);
             }
         }
-    };
-    if (DB) xload(0);
-#pragma unroll
-    for (int st = 0; st < NS; ++st) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (DB) { if (st + 1 < NS) xload(st + 1); }
-        else xload(st);
         __builtin_amdgcn_sched_barrier(0);
         const f16x8 w0 = wq[st % D][0], w1 = wq[st % D][1];
-        f16x8 (&xa)[KI] = xq[DB ? st & 1 : 0][0], (&xb)[KI] = xq[DB ? st & 1 : 0][1];
 #pragma unroll
         for (int k = 0; k < KI; ++k) if (k < KI - 1 || last) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, xa[k], acc[k], 0, 0, 0);
 #pragma unroll
@@ -99,10 +95,7 @@ __device__ __forceinline__ void rf_accumulate(const char *src, const unsigned sh
 #pragma unroll
         for (int k = 0; k < KI; ++k) if (k < KI - 1 || last) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, xb[k], acc[k], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (st + D < NS) {
-            wq[st % D][0] = wl[(size_t)(st + D) * (2 * NT * 64)];
-            wq[st % D][1] = wl[(size_t)(st + D) * (2 * NT * 64) + NT * 64];
-        }
+        if (st + D < NS) { wq[st % D][0] = wld(st + D, 0); wq[st % D][1] = wld(st + D, 1); }
     }
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -114,187 +107,184 @@ struct RbFuse32Dev {
     unsigned short *out; size_t out_stride;
     float *out_f32;
     unsigned *sat;
-    int H, W;
     const float *q, *bt, *dire;       // ATT: the attention trunk's input is built here, from the logits (conv_misc.hip: att_input_kernel)
     int layer;
 };
 
-// CB_IN input groups, NT output groups (= groups of the intermediate), POOLF: 2x2 max-pool and plain fp32 output (trunk_B3.2)
+// CB_IN input groups, NT output groups (= groups of the intermediate), POOLF: 2x2 max-pool and plain fp32 output (trunk_B3.2).
 // ATT (trunk_Att2.0): no input tensor at all - cat[up(q), up(bt[layer]), up(dire[layer])] (Model_QBD.py:147), three channels of a 16-channel
 // group, is computed from the logits into the halo image, with att_input_kernel's arithmetic (two-term split, clamp, range flag).
+// The map is 32 x 32 (S), four tiles per block.
+//
+// PERSISTENT: a workgroup walks a contiguous run of tiles (the tiles of a block - they share halo rows and columns - stay on one workgroup,
+// hence on one XCD's L2) and requests tile i+1's input into registers before it starts on tile i's convolutions.
+// VALU diet (the second form of this kernel spent 65 % of its cycles issuing ~820 non-MFMA vector instructions per wave and tile - address
+// arithmetic - with the matrix pipes 32 % busy): everything that does not depend on the tile is computed ONCE in front of the loop and is
+// small (window origins, one store offset, one weight offset: <= 12 registers); tile coordinates are scalar (the wave index comes from
+// v_readfirstlane, so output group and row band are SGPRs); global addresses are `uniform base + 32-bit lane offset` (the saddr form: no
+// 64-bit vector arithmetic); a thread stages ONE pixel of the halo image (all groups, planes, halves of it: offsets become immediates).
 template <int CB_IN, int NT, bool POOLF, bool ATT = false>
 __global__ __launch_bounds__(512, 4) void rbfuse32_kernel(RbFuse32Dev a, int total)
 {
+    constexpr int S = 32, TILES = 4, NPX = RF_IW * RF_IW;
     __shared__ __attribute__((aligned(16))) char img[CB_IN * RF_ISLOT];
     __shared__ __attribute__((aligned(16))) char timg[NT * RF_TSLOT];
-    int tid = threadIdx.x;
-    const int tiles_x = a.W >> 4, tiles = tiles_x * (a.H >> 4);
-    const int H = a.H, W = a.W;
-    // PERSISTENT: a workgroup walks a contiguous run of tiles (the tiles of a block - they share halo rows and columns - stay on one
-    // workgroup, hence on one XCD's L2) and requests tile i+1's input into registers before it starts on tile i's convolutions: the first
-    // form of this kernel (one tile per workgroup: load, wait, compute, store) spent more time waiting for its 51 KB than computing.
+    const int tid = threadIdx.x, lane = tid & 63, xl = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ct = wave % NT, wsub = wave / NT;
+    constexpr int WPG = 8 / NT;                                   // waves per output group
     const int per = (total + (int)gridDim.x - 1) / (int)gridDim.x;
     const int t_begin = (int)blockIdx.x * per, t_end = min(t_begin + per, total);
     if (t_begin >= t_end) return;
+    static_assert(!ATT || CB_IN == 1, "the attention input is one channel group");
+
+    // ---- tile-independent lane state
+    const bool hi = (g >> 1) != 0;
+    const unsigned wv = (unsigned)lane * 16u;
+    const int fpx = min(tid, NPX - 1), frow = fpx / RF_IW, fcol = fpx - frow * RF_IW;       // the halo-image pixel this thread stages
+    constexpr int KI1 = (RF_NT1 + WPG - 1) / WPG, KI2 = 16 / WPG;
+    static_assert((KI1 - 1) * WPG < RF_NT1, "only a wave's last item may fall outside the region");
+    const bool last1 = wsub + (KI1 - 1) * WPG < RF_NT1;
+    int pb1[KI1], pyx1[KI1];                                      // first convolution: window origin and (row | column << 8 | valid << 16) of each item's pixel
+#pragma unroll
+    for (int k = 0; k < KI1; ++k) {
+        const int pix = (wsub + k * WPG) * 16 + xl, p = min(pix, RF_TW * RF_TW - 1), py = p / RF_TW, px = p - py * RF_TW;
+        pb1[k] = (py * RF_IW + px) * 32 + (g & 1) * 16;
+        pyx1[k] = py | (px << 8) | ((pix < RF_TW * RF_TW) ? 1 << 16 : 0);
+    }
+    const int row0 = wsub * KI2;                                  // second convolution: this wave's KI2 consecutive rows
+    const int pb2[1] = {(row0 * RF_TW + xl) * 32 + (g & 1) * 16}, pbs[1] = {((row0 + 2) * RF_IW + xl + 2) * 32 + (g & 1) * 16};
+    const unsigned ov = POOLF ? (unsigned)(((row0 >> 1) * (S / 2) + (xl >> 1)) * 64 + g * 16)
+                              : (unsigned)(((row0 + (g & 1)) * S + xl) * 32 + 16 * (g >> 1));            // output byte offset inside (block, group, tile)
+    const char *w0b = reinterpret_cast<const char *>(a.w0) + ct * 1024, *w2b = reinterpret_cast<const char *>(a.w2) + ct * 1024,
+               *wsb = reinterpret_cast<const char *>(a.wsc) + ct * 1024;
 
     float amax = 0.f;
-    constexpr int PIECES = CB_IN * 2 * RF_IW * RF_IW * 2, NLD = ATT ? 1 : (PIECES + 511) / 512;
-    unsigned inmask = 0;
-    u32x4 r[NLD];          // the next tile's input on its way (ATT: the three logit values of this thread's pixel, and whether it is inside the map)
+    constexpr int NLD = ATT ? 1 : CB_IN * 4;
+    unsigned fin = 0;      // is the staged pixel inside the map (the tile in flight)
+    u32x4 r[NLD];          // the next tile's input on its way: [group][plane][half] of this thread's pixel (ATT: its three logit values)
     auto fetch = [&](int tl) __attribute__((always_inline)) {
-        const int n = tl / tiles, t = tl - n * tiles, ty = t / tiles_x, tx = t - ty * tiles_x;
+        const int n = tl / TILES, t = tl % TILES, ty = t >> 1, tx = t & 1;
+        const int gy = ty * 16 - 2 + frow, gx = tx * 16 - 2 + fcol;
+        fin = (gy >= 0 && gy < S && gx >= 0 && gx < S) ? 1u : 0u;
+        const int cy = min(max(gy, 0), S - 1), cx = min(max(gx, 0), S - 1);
         if (ATT) {
-            const int px = min(tid, RF_IW * RF_IW - 1);
-            const int row = px / RF_IW, col = px - row * RF_IW, gy = ty * 16 - 2 + row, gx = tx * 16 - 2 + col;
-            const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-            const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
-            const int sq = H / 8, sh = H / 16;
-            const size_t o = ((size_t)n * 3 + a.layer) * 256 + (cy / sh) * 16 + (cx / sh);
-            r[0] = (u32x4){__float_as_uint(a.q[(size_t)n * 64 + (cy / sq) * 8 + (cx / sq)]), __float_as_uint(a.bt[o]), __float_as_uint(a.dire[o]), in ? 1u : 0u};
+            const float *qb = a.q + (size_t)n * 64, *bb = a.bt + ((size_t)n * 3 + a.layer) * 256, *db = a.dire + ((size_t)n * 3 + a.layer) * 256;
+            const unsigned o = (unsigned)((cy >> 1) * 16 + (cx >> 1)) * 4u;
+            r[0] = (u32x4){*reinterpret_cast<const RF_GLOBAL unsigned *>((const RF_GLOBAL char *)qb + (unsigned)((cy >> 2) * 8 + (cx >> 2)) * 4u),
+                           *reinterpret_cast<const RF_GLOBAL unsigned *>((const RF_GLOBAL char *)bb + o),
+                           *reinterpret_cast<const RF_GLOBAL unsigned *>((const RF_GLOBAL char *)db + o), 0u};
         } else {
-            inmask = 0;
+            const unsigned vo = (unsigned)(cy * S + cx) * 32u;
 #pragma unroll
-            for (int k = 0; k < NLD; ++k) {
-                const int i = min(tid + k * 512, PIECES - 1);
-                const int half = i & 1, pix = (i >> 1) % (RF_IW * RF_IW), sp = ((i >> 1) / (RF_IW * RF_IW)) & 1, cb = (i >> 1) / (2 * RF_IW * RF_IW);
-                const int row = pix / RF_IW, col = pix - row * RF_IW, gy = ty * 16 - 2 + row, gx = tx * 16 - 2 + col;
-                const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-                const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
-                r[k] = *reinterpret_cast<const u32x4 *>(a.x + sp * a.x_stride + (((size_t)n * CB_IN + cb) * H + cy) * W * 16 + (size_t)cx * 16 + half * 8);
-                if (in) inmask |= 1u << k;     // applied when the data is used (stash): nothing here waits for the loads
-            }
+            for (int cb = 0; cb < CB_IN; ++cb)
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp) {
+                    const char *base = reinterpret_cast<const char *>(a.x + sp * a.x_stride + ((size_t)n * CB_IN + cb) * (S * S * 16));      // uniform
+                    r[(cb * 2 + sp) * 2 + 0] = *reinterpret_cast<const RF_GLOBAL u32x4 *>((const RF_GLOBAL char *)base + vo);
+                    r[(cb * 2 + sp) * 2 + 1] = *reinterpret_cast<const RF_GLOBAL u32x4 *>((const RF_GLOBAL char *)base + vo + 16);
+                }
         }
     };
     // registers -> LDS halo images (zero outside the map)
     auto stash = [&]() __attribute__((always_inline)) {
+        if (tid >= NPX) return;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        char *d = img + tid * 32;
         if (ATT) {
-            if (tid < RF_IW * RF_IW) {
-                u32x4 lo = {0u, 0u, 0u, 0u}, hi = {0u, 0u, 0u, 0u};
-                if (r[0].w) {
-                    const f32x4 v = {__uint_as_float(r[0].x), __uint_as_float(r[0].y), __uint_as_float(r[0].z), 0.f};
-                    amax = sat_amax4(amax, v);
-                    unsigned p0, q0, p1, q1;
-                    h2_split_pair(v.x, v.y, p0, q0);
-                    h2_split_pair(v.z, v.w, p1, q1);
-                    lo.x = p0; lo.y = p1; hi.x = q0; hi.y = q1;
-                }
-                const u32x4 z = {0u, 0u, 0u, 0u};
-                *reinterpret_cast<u32x4 *>(img + tid * 32) = lo;
-                *reinterpret_cast<u32x4 *>(img + tid * 32 + 16) = z;
-                *reinterpret_cast<u32x4 *>(img + RF_IPLN + tid * 32) = hi;
-                *reinterpret_cast<u32x4 *>(img + RF_IPLN + tid * 32 + 16) = z;
+            u32x4 lo = z, hi4 = z;
+            if (fin) {
+                const f32x4 v = {__uint_as_float(r[0].x), __uint_as_float(r[0].y), __uint_as_float(r[0].z), 0.f};
+                amax = sat_amax4(amax, v);
+                unsigned p0, q0, p1, q1;
+                h2_split_pair(v.x, v.y, p0, q0);
+                h2_split_pair(v.z, v.w, p1, q1);
+                lo.x = p0; lo.y = p1; hi4.x = q0; hi4.y = q1;
             }
+            *reinterpret_cast<u32x4 *>(d) = lo;
+            *reinterpret_cast<u32x4 *>(d + 16) = z;
+            *reinterpret_cast<u32x4 *>(d + RF_IPLN) = hi4;
+            *reinterpret_cast<u32x4 *>(d + RF_IPLN + 16) = z;
         } else {
 #pragma unroll
-            for (int k = 0; k < NLD; ++k) {
-                const int i = tid + k * 512;
-                if (i < PIECES) {
-                    const int half = i & 1, pix = (i >> 1) % (RF_IW * RF_IW), sp = ((i >> 1) / (RF_IW * RF_IW)) & 1, cb = (i >> 1) / (2 * RF_IW * RF_IW);
-                    const u32x4 z = {0u, 0u, 0u, 0u};
-                    *reinterpret_cast<u32x4 *>(img + cb * RF_ISLOT + sp * RF_IPLN + pix * 32 + half * 16) = ((inmask >> k) & 1u) ? r[k] : z;
-                }
-            }
+            for (int i = 0; i < NLD; ++i)
+                *reinterpret_cast<u32x4 *>(d + (i >> 2) * RF_ISLOT + ((i >> 1) & 1) * RF_IPLN + (i & 1) * 16) = fin ? r[i] : z;
         }
     };
-    static_assert(!ATT || CB_IN == 1, "the attention input is one channel group");
     fetch(t_begin);
   for (int tl = t_begin; tl < t_end; ++tl) {
-    // opaque per tile: otherwise hipcc hoists every lane-derived address of the loop body (piece decomposition, window origins, weight
-    // pointers: ~100 registers of loop invariants) in front of the loop and spills them
-    asm volatile("" : "+v"(tid));
-    const int lane = tid & 63, wave = tid >> 6, xl = lane & 15, g = lane >> 4;
-    const int n = tl / tiles, t = tl - n * tiles, ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int n = tl / TILES, t = tl % TILES, ty = t >> 1, tx = t & 1;
+    // opaque per tile: `uniform base + lane offset` must stay an addressing mode; as a loop invariant hipcc materialises it - one 64-bit
+    // vector address per weight fragment of every K-step - in front of the loop and spills it
+    unsigned wvt = wv, ovt = ov;
+    asm volatile("" : "+v"(wvt), "+v"(ovt));
     stash();
     __syncthreads();
     fetch(min(tl + 1, t_end - 1));        // (the last tile is requested twice: the loads stay unconditional)
 
-    const int ct = wave % NT, wsub = wave / NT;
-    constexpr int WPG = 8 / NT;                                   // waves per output group
     // ---- first convolution on the 18x18 region: wave (ct, wsub) takes the columns-of-16 wsub, wsub + WPG, ...
     {
-        constexpr int KI = (RF_NT1 + WPG - 1) / WPG;
-        static_assert((KI - 1) * WPG < RF_NT1, "only a wave's last item may fall outside the region");
-        int pb[KI], pix[KI];
-        const bool last = wsub + (KI - 1) * WPG < RF_NT1;
+        f32x4 acc[KI1];
 #pragma unroll
-        for (int k = 0; k < KI; ++k) {
-            const int tile = wsub + k * WPG;
-            const int p = min(tile * 16 + xl, RF_TW * RF_TW - 1);
-            pix[k] = tile * 16 + xl;
-            pb[k] = ((p / RF_TW) * RF_IW + p % RF_TW) * 32 + (g & 1) * 16;
-        }
-        f32x4 acc[KI];
+        for (int k = 0; k < KI1; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        rf_accumulate<9, CB_IN, NT, KI1, RF_IW, RF_ISLOT, RF_IPLN, 0, KI1>(img, w0b, wvt, hi, pb1, last1, acc);
+        const int oy = ty * 16 - 1, ox = tx * 16 - 1;
 #pragma unroll
-        for (int k = 0; k < KI; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        rf_accumulate<9, CB_IN, NT, KI, RF_IW, RF_ISLOT, RF_IPLN>(img, a.w0, lane, ct, pb, last, acc);
-#pragma unroll
-        for (int k = 0; k < KI; ++k) {
-            if ((k == KI - 1 && !last) || pix[k] >= RF_TW * RF_TW) continue;
-            const int py = pix[k] / RF_TW, px = pix[k] - py * RF_TW, gy = ty * 16 - 1 + py, gx = tx * 16 - 1 + px;
+        for (int k = 0; k < KI1; ++k) {
+            if ((k == KI1 - 1 && !last1) || !(pyx1[k] >> 16)) continue;
+            const int py = pyx1[k] & 255, px = (pyx1[k] >> 8) & 255;
             f32x4 v = acc[k] * a.s0;
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            if (!(gy >= 0 && gy < H && gx >= 0 && gx < W)) v = (f32x4){0.f, 0.f, 0.f, 0.f};      // the second convolution's zero padding
+            if ((unsigned)(oy + py) >= (unsigned)S || (unsigned)(ox + px) >= (unsigned)S) v = (f32x4){0.f, 0.f, 0.f, 0.f};      // the second convolution's zero padding
             amax = sat_amax4(amax, v);
             unsigned p0, q0, p1, q1;
             h2_split_pair(v.x, v.y, p0, q0);
             h2_split_pair(v.z, v.w, p1, q1);
-            char *dp = timg + ct * RF_TSLOT + pix[k] * 32 + g * 8;
+            char *dp = timg + ct * RF_TSLOT + (py * RF_TW + px) * 32 + g * 8;
             *reinterpret_cast<u32x2_t *>(dp) = (u32x2_t){p0, p1};
             *reinterpret_cast<u32x2_t *>(dp + RF_TPLN) = (u32x2_t){q0, q1};
         }
     }
     __syncthreads();
 
-    // ---- second convolution + 1x1 shortcut on the 16x16 tile: wave (ct, wsub) takes the KI consecutive rows KI * wsub ..
+    // ---- second convolution + 1x1 shortcut on the 16x16 tile: wave (ct, wsub) takes the KI2 consecutive rows row0 ..
     {
-        constexpr int KI = 16 / WPG;
-        int pb[KI], pbs[KI];
+        f32x4 acc[KI2];
 #pragma unroll
-        for (int k = 0; k < KI; ++k) {
-            const int row = wsub * KI + k;
-            pb[k] = (row * RF_TW + xl) * 32 + (g & 1) * 16;
-            pbs[k] = ((row + 2) * RF_IW + xl + 2) * 32 + (g & 1) * 16;
-        }
-        f32x4 acc[KI];
+        for (int k = 0; k < KI2; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        rf_accumulate<9, NT, NT, KI2, RF_TW, RF_TSLOT, RF_TPLN, RF_TW * 32, 1>(timg, w2b, wvt, hi, pb2, true, acc);
+        rf_accumulate<1, CB_IN, NT, KI2, RF_IW, RF_ISLOT, RF_IPLN, RF_IW * 32, 1>(img, wsb, wvt, hi, pbs, true, acc);       // ResidualBlock, Model_QBD.py:33-38
 #pragma unroll
-        for (int k = 0; k < KI; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        rf_accumulate<9, NT, NT, KI, RF_TW, RF_TSLOT, RF_TPLN>(timg, a.w2, lane, ct, pb, true, acc);
-        rf_accumulate<1, CB_IN, NT, KI, RF_IW, RF_ISLOT, RF_IPLN>(img, a.wsc, lane, ct, pbs, true, acc);       // ResidualBlock, Model_QBD.py:33-38
-#pragma unroll
-        for (int k = 0; k < KI; ++k) {
+        for (int k = 0; k < KI2; ++k) {
             f32x4 v = acc[k] * a.s2;
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             if (!POOLF) amax = sat_amax4(amax, v);      // a plain fp32 output is not clamped: not the range flag's business (conv_f16x3.hip)
             acc[k] = v;
         }
-        const int row0 = wsub * KI;
         if (POOLF) {
-            const int Ho = H >> 1, Wo = W >> 1;
+            char *ob = reinterpret_cast<char *>(a.out_f32 + (((size_t)n * NT + ct) * (S / 2) + ty * 8) * (S / 2) * 16 + tx * 8 * 16);     // uniform
 #pragma unroll
-            for (int k = 0; k < KI; k += 2) {
+            for (int k = 0; k < KI2; k += 2) {
                 f32x4 v = acc[k], u = acc[k + 1];
                 v.x = fmaxf(v.x, u.x); v.y = fmaxf(v.y, u.y); v.z = fmaxf(v.z, u.z); v.w = fmaxf(v.w, u.w);
                 f32x4 o;
                 o.x = __shfl_xor(v.x, 1); o.y = __shfl_xor(v.y, 1); o.z = __shfl_xor(v.z, 1); o.w = __shfl_xor(v.w, 1);
                 v.x = fmaxf(v.x, o.x); v.y = fmaxf(v.y, o.y); v.z = fmaxf(v.z, o.z); v.w = fmaxf(v.w, o.w);
-                if ((xl & 1) == 0) {
-                    const int yo = ty * 8 + ((row0 + k) >> 1), xo = tx * 8 + (xl >> 1);
-                    *reinterpret_cast<f32x4 *>(a.out_f32 + ((((size_t)n * NT + ct) * Ho + yo) * Wo + xo) * 16 + g * 4) = v;
-                }
+                if ((xl & 1) == 0) *reinterpret_cast<RF_GLOBAL f32x4 *>((RF_GLOBAL char *)ob + ovt + (k >> 1) * ((S / 2) * 64)) = v;
             }
         } else {
             // 16-byte stores as conv_f16x3.hip's epilogue: one v_permlane16_swap per register turns {rows m, m+1} x {couts 4g..} into the 8
             // consecutive channels 8(g>>1).. of row m + (g&1)
+            char *ob = reinterpret_cast<char *>(a.out + (((size_t)n * NT + ct) * S + ty * 16) * S * 16 + tx * 16 * 16);                      // uniform
+            char *ob1 = ob + a.out_stride * 2;
 #pragma unroll
-            for (int k = 0; k < KI; k += 2) {
+            for (int k = 0; k < KI2; k += 2) {
                 u32x4 p, q;
                 split2_rows(acc[k], acc[k + 1], p, q);
                 rows16_swap(p);
                 rows16_swap(q);
-                const int gy = ty * 16 + row0 + k + (g & 1), gx = tx * 16 + xl;
-                unsigned short *op = a.out + ((((size_t)n * NT + ct) * H + gy) * W + gx) * 16 + 8 * (g >> 1);
-                __builtin_nontemporal_store(p, reinterpret_cast<u32x4 *>(op));
-                __builtin_nontemporal_store(q, reinterpret_cast<u32x4 *>(op + a.out_stride));
+                __builtin_nontemporal_store(p, reinterpret_cast<RF_GLOBAL u32x4 *>((RF_GLOBAL char *)ob + ovt + k * (S * 32)));
+                __builtin_nontemporal_store(q, reinterpret_cast<RF_GLOBAL u32x4 *>((RF_GLOBAL char *)ob1 + ovt + k * (S * 32)));
             }
         }
     }
@@ -307,9 +297,9 @@ __global__ __launch_bounds__(512, 4) void rbfuse32_kernel(RbFuse32Dev a, int tot
 
 hipError_t launch_rbfuse32(hipStream_t s, const RbFuse32Args &h)
 {
-    if ((h.H & 15) || (h.W & 15) || h.N <= 0) return hipErrorInvalidValue;
-    RbFuse32Dev a{h.x, h.x_stride, h.w0, h.w2, h.wsc, h.s0, h.s2, h.out, h.out_stride, h.out_f32, h.sat, h.H, h.W, h.q, h.bt, h.dire, h.att_layer};
-    const int total = h.N * ((h.H >> 4) * (h.W >> 4));
+    if (h.H != 32 || h.W != 32 || h.N <= 0) return hipErrorInvalidValue;
+    RbFuse32Dev a{h.x, h.x_stride, h.w0, h.w2, h.wsc, h.s0, h.s2, h.out, h.out_stride, h.out_f32, h.sat, h.q, h.bt, h.dire, h.att_layer};
+    const int total = h.N * 4;
     const unsigned grid = (unsigned)(total < RF_GRID ? total : RF_GRID);       // persistent: two workgroups per CU, each a contiguous run of tiles
     if (!h.x) {
         if (!h.q || !h.bt || !h.dire || h.cin_groups != 1 || h.cout_groups != 2 || h.pool_f32) return hipErrorInvalidValue;
