@@ -72,29 +72,38 @@ __device__ __forceinline__ void rf_accumulate(const char *src, const char *wbase
     f16x8 wq[D][2];
 #pragma unroll
     for (int st = 0; st < D; ++st) { wq[st][0] = wld(st, 0); wq[st][1] = wld(st, 1); }
+    // Rolling pixel fragments, no second register set: a K-step's high-term fragments xa are re-requested for the NEXT K-step as soon as the
+    // two MFMA groups that read them have issued, its low-term fragments xb after the third group - the LDS round trip of one runs behind
+    // the MFMAs of the other (eight waves per workgroup, two workgroups per CU: nobody else hides it).
     f16x8 xa[KI], xb[KI];
-#pragma unroll
-    for (int st = 0; st < NS; ++st) {
+    auto soff = [&](int st) __attribute__((always_inline)) {
         int off = hi ? rf_step_off<T, CB, IMW, SLOT>(st, 1) : rf_step_off<T, CB, IMW, SLOT>(st, 0);
         asm volatile("" : "+v"(off));      // opaque: keeps hipcc from hoisting the addresses of every K-step and item out of the pass
-        __builtin_amdgcn_sched_barrier(0);
+        return off;
+    };
+    auto rd = [&](f16x8 (&x)[KI], int off, int plane) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 0; k < KI; ++k) {
-            if (k < KI - 1 || last) {
-                const char *p = src + (ISTR ? pb[0] + k * ISTR : pb[ISTR ? 0 : k]) + off;
-                xa[k] = *reinterpret_cast<const f16x8 *>(p);
-                xb[k] = *reinterpret_cast<const f16x8 *>(p + PLN);
-            }
-        }
+        for (int k = 0; k < KI; ++k)
+            if (k < KI - 1 || last) x[k] = *reinterpret_cast<const f16x8 *>(src + (ISTR ? pb[0] + k * ISTR : pb[ISTR ? 0 : k]) + off + plane * PLN);
+    };
+    int off = soff(0);
+    rd(xa, off, 0);
+    rd(xb, off, 1);
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
         __builtin_amdgcn_sched_barrier(0);
         const f16x8 w0 = wq[st % D][0], w1 = wq[st % D][1];
 #pragma unroll
         for (int k = 0; k < KI; ++k) if (k < KI - 1 || last) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, xa[k], acc[k], 0, 0, 0);
 #pragma unroll
         for (int k = 0; k < KI; ++k) if (k < KI - 1 || last) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, xa[k], acc[k], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 1 < NS) { off = soff(st + 1); rd(xa, off, 0); }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < KI; ++k) if (k < KI - 1 || last) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, xb[k], acc[k], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+        if (st + 1 < NS) rd(xb, off, 1);
         if (st + D < NS) { wq[st % D][0] = wld(st + D, 0); wq[st % D][1] = wld(st + D, 1); }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -222,27 +231,35 @@ __global__ __launch_bounds__(512, 4) void rbfuse32_kernel(RbFuse32Dev a, int tot
     __syncthreads();
     fetch(min(tl + 1, t_end - 1));        // (the last tile is requested twice: the loads stay unconditional)
 
-    // ---- first convolution on the 18x18 region: wave (ct, wsub) takes the columns-of-16 wsub, wsub + WPG, ...
+    // ---- first convolution on the 18x18 region: wave (ct, wsub) takes the columns-of-16 wsub, wsub + WPG, ... - three at a time (six
+    //      accumulators with their fragments do not fit next to the prefetched tile: the second trio re-reads the weight fragments from L1)
     {
-        f32x4 acc[KI1];
-#pragma unroll
-        for (int k = 0; k < KI1; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        rf_accumulate<9, CB_IN, NT, KI1, RF_IW, RF_ISLOT, RF_IPLN, 0, KI1>(img, w0b, wvt, hi, pb1, last1, acc);
+        constexpr int KC = 3;
+        static_assert(KI1 % KC == 0, "items in trios");
         const int oy = ty * 16 - 1, ox = tx * 16 - 1;
 #pragma unroll
-        for (int k = 0; k < KI1; ++k) {
-            if ((k == KI1 - 1 && !last1) || !(pyx1[k] >> 16)) continue;
-            const int py = pyx1[k] & 255, px = (pyx1[k] >> 8) & 255;
-            f32x4 v = acc[k] * a.s0;
-            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            if ((unsigned)(oy + py) >= (unsigned)S || (unsigned)(ox + px) >= (unsigned)S) v = (f32x4){0.f, 0.f, 0.f, 0.f};      // the second convolution's zero padding
-            amax = sat_amax4(amax, v);
-            unsigned p0, q0, p1, q1;
-            h2_split_pair(v.x, v.y, p0, q0);
-            h2_split_pair(v.z, v.w, p1, q1);
-            char *dp = timg + ct * RF_TSLOT + (py * RF_TW + px) * 32 + g * 8;
-            *reinterpret_cast<u32x2_t *>(dp) = (u32x2_t){p0, p1};
-            *reinterpret_cast<u32x2_t *>(dp + RF_TPLN) = (u32x2_t){q0, q1};
+        for (int c = 0; c < KI1; c += KC) {
+            f32x4 acc[KC];
+            int pbc[KC];
+#pragma unroll
+            for (int k = 0; k < KC; ++k) { acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f}; pbc[k] = pb1[c + k]; }
+            const bool lastc = c + KC < KI1 ? true : last1;
+            rf_accumulate<9, CB_IN, NT, KC, RF_IW, RF_ISLOT, RF_IPLN, 0, KC>(img, w0b, wvt, hi, pbc, lastc, acc);
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                if ((k == KC - 1 && !lastc) || !(pyx1[c + k] >> 16)) continue;
+                const int py = pyx1[c + k] & 255, px = (pyx1[c + k] >> 8) & 255;
+                f32x4 v = acc[k] * a.s0;
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                if ((unsigned)(oy + py) >= (unsigned)S || (unsigned)(ox + px) >= (unsigned)S) v = (f32x4){0.f, 0.f, 0.f, 0.f};      // the second convolution's zero padding
+                amax = sat_amax4(amax, v);
+                unsigned p0, q0, p1, q1;
+                h2_split_pair(v.x, v.y, p0, q0);
+                h2_split_pair(v.z, v.w, p1, q1);
+                char *dp = timg + ct * RF_TSLOT + (py * RF_TW + px) * 32 + g * 8;
+                *reinterpret_cast<u32x2_t *>(dp) = (u32x2_t){p0, p1};
+                *reinterpret_cast<u32x2_t *>(dp + RF_TPLN) = (u32x2_t){q0, q1};
+            }
         }
     }
     __syncthreads();
