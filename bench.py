@@ -121,11 +121,37 @@ def cpu_worker(blocks, seed, threads):
     q, b, d = O.infer_qbd(wq, wbd, x[:8], True, batch=8)
     P.seq_post_process(q, b, d, "Luma", 1, 64 * 8, 64, None)
     print("ready", flush=True)
-    sys.stdin.readline()
+    budget = float(sys.stdin.readline().split()[1])           # "go <seconds>": work in batches of 16 blocks until the budget is used up
     t0 = time.time()
-    q, b, d = O.infer_qbd(wq, wbd, x, True, batch=64)
-    P.seq_post_process(q, b, d, "Luma", 1, 64 * blocks, 64, None)
-    print("done %.6f %.6f %d" % (t0, time.time(), blocks), flush=True)
+    done = 0
+    while done < blocks and (done == 0 or time.time() - t0 < budget):
+        m = min(16, blocks - done)
+        q, b, d = O.infer_qbd(wq, wbd, x[done:done + m], True, batch=16)
+        P.seq_post_process(q, b, d, "Luma", 1, 64 * m, 64, None)
+        done += m
+    print("done %.6f %.6f %d" % (t0, time.time(), done), flush=True)
+
+
+def cpu_limits():
+    """What the box lets this job use: scheduler affinity and the cgroup CPU quota (cores; None = unlimited / unreadable)."""
+    out = {"affinity": None, "cgroup_quota_cores": None}
+    try:
+        out["affinity"] = len(os.sched_getaffinity(0))
+    except Exception:      # noqa: BLE001
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                out["cgroup_quota_cores"] = None if txt[0] == "max" else round(int(txt[0]) / int(txt[1]), 2)
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                out["cgroup_quota_cores"] = None if q < 0 else round(q / per, 2)
+            break
+        except Exception:  # noqa: BLE001
+            continue
+    return out
 
 
 def cpu_all_cores(threads, ncpu, seed, s_per_block):
@@ -135,8 +161,10 @@ def cpu_all_cores(threads, ncpu, seed, s_per_block):
     so the reference's CPU path shards the same way)."""
     import subprocess
     procs_n = max(1, ncpu // max(threads, 1))
-    # ~15 s per worker at the single-process rate (workers slow each other down: shared caches, memory bandwidth)
-    blocks = max(16, min(256, int(15.0 / max(s_per_block, 1e-3)) // 8 * 8))
+    # every worker runs for a fixed budget of wall time (workers slow each other down - shared caches, memory bandwidth, a CPU quota of
+    # the container - so a fixed block count would make this leg's duration unpredictable); a generous supply of blocks each
+    budget_s = 15.0
+    blocks = max(16, min(1024, int(2 * budget_s / max(s_per_block, 1e-3)) // 16 * 16))
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", "%d,%d,%d" % (blocks, seed + 100 + i, threads)],
                               stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True) for i in range(procs_n)]
@@ -145,7 +173,7 @@ def cpu_all_cores(threads, ncpu, seed, s_per_block):
             if p.stdout.readline().strip() != "ready":
                 raise RuntimeError("a CPU worker did not come up")
         for p in procs:
-            p.stdin.write("go\n"); p.stdin.flush()
+            p.stdin.write("go %g\n" % budget_s); p.stdin.flush()
         wins = []
         for p in procs:
             tok = p.stdout.readline().split()
@@ -163,10 +191,13 @@ def cpu_all_cores(threads, ncpu, seed, s_per_block):
     wall = max(w[1] for w in wins) - min(w[0] for w in wins)
     total = sum(w[2] for w in wins)
     log("cpu_baseline: whole host: %d processes x %d threads, %d blocks in %.2f s" % (procs_n, threads, total, wall))
-    return {"processes": procs_n, "threads_each": threads, "cores_used": procs_n * threads, "host_cores": ncpu, "blocks": total,
+    lim = cpu_limits()
+    return {"processes": procs_n, "threads_each": threads, "cores_used": procs_n * threads, "host_cores": ncpu, "cpu_limits": lim, "blocks": total,
             "blocks_per_s": round(total / wall, 2), "value": round(total / 4.0 / wall, 3), "unit": "CTU/s", "wall_s": round(wall, 2),
             "note": "fresh worker processes (torch CPU only), each the single-process configuration above on its own recipe-R slice, released "
-                    "together; rate = all blocks / (last end - first start)"}
+                    "together for %g s of wall time each; rate = all blocks / (last end - first start).  If this is no more than the single "
+                    "process's rate, the box does not give this job more cores than one process already uses (cpu_limits: scheduler affinity "
+                    "and the cgroup's CPU quota)" % budget_s}
 
 
 def trained_like_extra(eng, dev, n, step, timed):

@@ -22,7 +22,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "rbfuse32" not in k and "conv_h2_kernel<3, 3, 2" not in k and "conv_h2_kernel<3, 3, 1" not in k: continue
+        if not any(t in k for t in ("rbfuse32", "branch16", "tail16", "stem_mfma", "postprocess_kernel", "conv_h2_kernel<3, 3, 2")): continue
         k = k.replace("pmp::(anonymous namespace)::", "").replace("void ", "").split("(")[0]
         a = acc[k][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
 for k in sorted(acc):
