@@ -32,6 +32,7 @@ struct MsbdBranch16Args {
     C16RB b1[3], att[2], b2[3];
     const float *head_w[2], *head_b[2];
     unsigned *sat;
+    float att_scale;
 };
 
 __global__ __launch_bounds__(512, 2) void msbd_branch16_kernel(MsbdBranch16Args a)
@@ -74,7 +75,8 @@ __global__ __launch_bounds__(512, 2) void msbd_branch16_kernel(MsbdBranch16Args 
     // attention input cat[up2(q), out0] (conv_misc.hip: att_input_kernel, S = 16) -> S0, channels 3..15 zero
     if (tid < 256) {
         const int x = tid & 15, y = tid >> 4;
-        const f32x4 v = {a.qt[(size_t)n * 64 + (y >> 1) * 8 + (x >> 1)], s_bt[tid], s_dire[tid], 0.f};
+        f32x4 v = {a.qt[(size_t)n * 64 + (y >> 1) * 8 + (x >> 1)], s_bt[tid], s_dire[tid], 0.f};
+        v *= a.att_scale;      // the attention segment's activation scale (a power of two: exact)
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         amax = c16_store_split(S0, 0, tid, 0, v, amax);
         c16_store_split(S0, 0, tid, 4, z, 0.f);
@@ -238,7 +240,7 @@ hipError_t launch_msbd_branch16(hipStream_t s, const Chain16MsbdArgs &h)
 {
     if (h.N <= 0) return hipErrorInvalidValue;
     MsbdBranch16Args a{};
-    a.x5 = h.x5; a.x5_stride = h.x5_stride; a.qt = h.qt; a.bt = h.bt; a.dire = h.dire; a.sat = h.sat;
+    a.x5 = h.x5; a.x5_stride = h.x5_stride; a.qt = h.qt; a.bt = h.bt; a.dire = h.dire; a.sat = h.sat; a.att_scale = h.att_scale;
     for (int i = 0; i < 3; ++i) {
         a.b1[i] = C16RB{h.b1[i].w0, h.b1[i].w2, h.b1[i].wsc, h.b1[i].s0, h.b1[i].s2};
         a.b2[i] = C16RB{h.b2[i].w0, h.b2[i].w2, h.b2[i].wsc, h.b2[i].s0, h.b2[i].s2};

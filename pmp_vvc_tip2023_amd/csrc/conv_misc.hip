@@ -559,7 +559,7 @@ hipError_t launch_multipool_concat(hipStream_t s, const float *x5, float *x6, in
 
 __global__ __launch_bounds__(256) void att_input_kernel(const float *__restrict__ q, const float *__restrict__ bt,
                                                         const float *__restrict__ dire, int layer, ActOut out, int N,
-                                                        int S)
+                                                        int S, float scale)
 {
     const size_t total = (size_t)N * S * S;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -568,16 +568,17 @@ __global__ __launch_bounds__(256) void att_input_kernel(const float *__restrict_
     const int sq = S / 8, sh = S / 16;
     const size_t o = ((size_t)n * 3 + layer) * 256 + (y / sh) * 16 + (x / sh);
     f32x4 v = {q[(size_t)n * 64 + (y / sq) * 8 + (x / sq)], bt[o], dire[o], 0.f};
+    v *= scale;        // f16x3 activation scale of the attention segment: a power of two (exact), 1 elsewhere
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     out.store4(i * 16, v); out.store4(i * 16 + 4, z); out.store4(i * 16 + 8, z); out.store4(i * 16 + 12, z);
 }
 
 hipError_t launch_att_input(hipStream_t s, const float *q, const float *bt, const float *dire, int layer, float *out,
-                            int N, int S, unsigned short *out_s3, size_t s3_stride, int fmt, unsigned *sat)
+                            int N, int S, unsigned short *out_s3, size_t s3_stride, int fmt, unsigned *sat, float scale)
 {
     const size_t total = (size_t)N * S * S;
     hipLaunchKernelGGL(att_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, q, bt, dire, layer,
-                       ActOut{out, out_s3, s3_stride, fmt, sat}, N, S);
+                       ActOut{out, out_s3, s3_stride, fmt, sat}, N, S, scale);
     return hipGetLastError();
 }
 

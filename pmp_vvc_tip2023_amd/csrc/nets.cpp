@@ -218,7 +218,7 @@ struct Graph {
             RbFuse32Args a{};
             a.w0 = r.w0h; a.w2 = r.w2h; a.wsc = r.wsch; a.s0 = std::ldexp(1.f, -r.k0); a.s2 = std::ldexp(1.f, -r.k2);
             a.out = y.s(); a.out_stride = y.stride; a.sat = sat(); a.N = n; a.H = S; a.W = S; a.cin_groups = 1; a.cout_groups = 2;
-            a.q = q; a.bt = bt; a.dire = dire; a.att_layer = layer;
+            a.q = q; a.bt = bt; a.dire = dire; a.att_layer = layer; a.att_scale = std::ldexp(1.f, -E(seg));
             KScope ks(c, K_CONV_OTHER, 2.0 * n * S * S * r.cout * (r.cin * 9 + r.cout * 9 + r.cin));
             check(launch_rbfuse32(c->stream, a), "rbfuse32(att)");
         }
@@ -335,6 +335,7 @@ int forward_msbd(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, 
         if (!ok) return g.rc;
         a.x5 = x5.s(); a.x5_stride = x5.stride; a.qt = qt; a.bt = bt; a.dire = dire; a.N = n; a.sat = g.sat();
         a.att[1].s2 = std::ldexp(a.att[1].s2, g.E(1) + g.E(0) - g.E(2));     // the gate product x5 * att0: from segments 1 and 0 into segment 2
+        a.att_scale = std::ldexp(1.f, -g.E(1));
         for (int i = 0; i < 2; ++i) { a.head_w[i] = g.head_weights(i, i); a.head_b[i] = w.head_b[i]; }
         if (g.live()) {
             KScope ks(c, K_CONV_OTHER, flops);
@@ -353,7 +354,7 @@ int forward_msbd(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, 
         Act ai = g.alloc(16, 16, 16, g.x6());
         if (g.live()) {
             KScope ks(c, K_SMALL, 0.0);
-            g.check(launch_att_input(c->stream, qt, bt, dire, 0, ai.split ? nullptr : ai.p, n, 16, ai.split ? ai.s() : nullptr, ai.stride, g.fmt(), g.sat()), "att_input");
+            g.check(launch_att_input(c->stream, qt, bt, dire, 0, ai.split ? nullptr : ai.p, n, 16, ai.split ? ai.s() : nullptr, ai.stride, g.fmt(), g.sat(), std::ldexp(1.f, -g.E(1))), "att_input");
         }
         g.note(ai, "att_input1", 1);
         Act a1 = g.rb(ai, "trunk_Att1.0");
@@ -375,7 +376,7 @@ int forward_msbd(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, 
         Act aj = g.alloc(16, 32, 32, g.x6());
         if (g.live()) {
             KScope ks(c, K_SMALL, 0.0);
-            g.check(launch_att_input(c->stream, qt, bt, dire, 1, aj.split ? nullptr : aj.p, n, 32, aj.split ? aj.s() : nullptr, aj.stride, g.fmt(), g.sat()), "att_input");
+            g.check(launch_att_input(c->stream, qt, bt, dire, 1, aj.split ? nullptr : aj.p, n, 32, aj.split ? aj.s() : nullptr, aj.stride, g.fmt(), g.sat(), std::ldexp(1.f, -g.E(3))), "att_input");
         }
         g.note(aj, "att_input2", 3);
         a2 = g.rb(aj, "trunk_Att2.0");

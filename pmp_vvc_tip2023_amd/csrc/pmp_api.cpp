@@ -192,8 +192,8 @@ static void make_calibration_blocks(std::vector<uint8_t> &y, std::vector<uint8_t
 
 // Runs the (QT, MTT) pair of a component once on the calibration blocks - on the fp32 MFMA datapath, launch per layer, with the largest
 // |value| of every MTT tensor recorded (nets.cpp: Graph::note) - and derives the segment exponents of the f16x3 datapath from them:
-// e = the smallest exponent >= 0 that brings the segment's maximum to 2^PMP_CAL_TARGET_EXP or below.  The attention trunks (segments
-// 1 and 3) start from logits and keep e = 0.  Synchronises the stream (once per net: first use on the f16x3 datapath).
+// e = the smallest exponent >= 0 that brings the segment's maximum to 2^PMP_CAL_TARGET_EXP or below (the attention trunks, segments 1 and
+// 3, take theirs where their input is built from the logits).  Synchronises the stream (once per net: first use on the f16x3 datapath).
 static int calibrate_mtt(pmp_ctx *c, bool luma, NetWeights &wq, NetWeights &wb)
 {
     int rc;
@@ -246,7 +246,7 @@ static int calibrate_mtt(pmp_ctx *c, bool luma, NetWeights &wq, NetWeights &wb)
         if (sg >= 0 && sg < 5 && (m > seg_max[sg] || m != m)) seg_max[sg] = m;
     }
     int exps[5] = {0, 0, 0, 0, 0};
-    for (int sg = 0; sg < 5; sg += 2) {        // a NaN / inf maximum leaves e = 0: that net needs the range guard's fp32 re-run anyway
+    for (int sg = 0; sg < 5; ++sg) {           // a NaN / inf maximum leaves e = 0: that net needs the range guard's fp32 re-run anyway
         const float m = seg_max[sg];
         if (!(m == m) || std::isinf(m)) continue;
         int ex = 0;

@@ -51,11 +51,11 @@ struct NetWeights {
     // f16x3 ACTIVATION SCALES (MTT nets; include/pmp.h).  The net is bias-free behind its stems and ReLU, max-pool and the gate product are
     // positively homogeneous, so a tensor may travel as true * 2^-e - exactly, a power of two commutes with every rounding - as long as
     // whoever consumes it knows e.  One exponent per SEGMENT of the graph (Model_QBD.py:127-155):
-    //   0  stem .. trunk_M1 .. trunk_M2 .. trunk_B1          1  attention trunk 1 (its input is built from logits: e = 0)
-    //   2  x5 * att0 .. trunk_B2                              3  attention trunk 2 (e = 0)          4  x4 * att1 .. trunk_B3
-    // and the changes of scale cost nothing at run time: 2^-e0 is folded into the stem's output scale and biases (stem_b_h), the step at a
-    // gate product into the out_scale of the convolution whose epilogue multiplies (nets.cpp), the way back into the head weights
-    // (head_w_h = head_w * 2^e).  The exponents come from a calibration pass on the library's own extreme-content blocks, run once when
+    //   0  stem .. trunk_M1 .. trunk_M2 .. trunk_B1          1  attention trunk 1 (input built from logits)
+    //   2  x5 * att0 .. trunk_B2                              3  attention trunk 2                  4  x4 * att1 .. trunk_B3
+    // and the changes of scale cost nothing at run time: 2^-e0 is folded into the stem's output scale and biases (stem_b_h), 2^-e1 / 2^-e3
+    // into the attention inputs where they are built, the step at a gate product into the out_scale of the convolution whose epilogue
+    // multiplies (nets.cpp), the way back into the head weights (head_w_h = head_w * 2^e).  The exponents come from a calibration pass on the library's own extreme-content blocks, run once when
     // the net is first used on the f16x3 datapath (pmp_api.cpp: calibrate_mtt); all zero = the arithmetic of a net without scales, bit for bit.
     int act_exp[5] = {0, 0, 0, 0, 0};
     bool calibrated = false;

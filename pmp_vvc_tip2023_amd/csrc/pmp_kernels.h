@@ -68,6 +68,7 @@ struct Chain16MsbdArgs {
     const float *head_w[2], *head_b[2];             // conv_B1, conv_B2: [9][8][2] + [2]
     unsigned *sat;
     int N;
+    float att_scale;                                // f16x3 activation scale of attention segment 1 (2^-e1; the attention input is built in the kernel)
 };
 hipError_t launch_msbd_branch16(hipStream_t s, const Chain16MsbdArgs &a);
 // QT nets: resblock_q3 -> multi-scale pool -> resblock_q4 -> resblock_q5 + max_pool2d(2) -> resblock_q6 (8x8, fp32 direct) -> conv_q2
@@ -97,6 +98,7 @@ struct RbFuse32Args {
     // x == nullptr (trunk_Att2.0 only): the block's input is the attention input cat[up(q), up(bt[att_layer]), up(dire[att_layer])], built in
     // the kernel from the logits q [N][64], bt / dire [N][3][256] (launch_att_input's arithmetic)
     const float *q, *bt, *dire; int att_layer;
+    float att_scale;                                 // ... times the f16x3 activation scale of its segment (2^-e3)
 };
 hipError_t launch_rbfuse32(hipStream_t s, const RbFuse32Args &a);
 
@@ -149,7 +151,8 @@ hipError_t launch_multipool_concat(hipStream_t s, const float *x5, float *x6, in
 // Attention trunk input (Model_QBD.py:140, :147): [N][1][S][S][16] with ch0 = up(q) (S/8 nearest), ch1 = bt[n][layer],
 // ch2 = dire[n][layer] (both 16x16, nearest-upsampled to S), channels 3..15 zero.
 hipError_t launch_att_input(hipStream_t s, const float *q, const float *bt, const float *dire, int layer, float *out,
-                            int N, int S, unsigned short *out_s3 = nullptr, size_t s3_stride = 0, int fmt = 1, unsigned *sat = nullptr);
+                            int N, int S, unsigned short *out_s3 = nullptr, size_t s3_stride = 0, int fmt = 1, unsigned *sat = nullptr,
+                            float scale = 1.f);     // scale: the f16x3 activation scale of the attention segment (a power of two)
 
 // Largest |value| of an fp32 tensor (n a multiple of 4), atomicMax'ed into *slot as the bit pattern of the magnitude: the calibration
 // pass of the f16x3 activation scales (pmp_api.cpp: calibrate_mtt).

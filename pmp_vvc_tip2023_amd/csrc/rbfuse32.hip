@@ -118,6 +118,7 @@ struct RbFuse32Dev {
     unsigned *sat;
     const float *q, *bt, *dire;       // ATT: the attention trunk's input is built here, from the logits (conv_misc.hip: att_input_kernel)
     int layer;
+    float att_scale;
 };
 
 // CB_IN input groups, NT output groups (= groups of the intermediate), POOLF: 2x2 max-pool and plain fp32 output (trunk_B3.2).
@@ -203,7 +204,8 @@ __global__ __launch_bounds__(512, 4) void rbfuse32_kernel(RbFuse32Dev a, int tot
         if (ATT) {
             u32x4 lo = z, hi4 = z;
             if (fin) {
-                const f32x4 v = {__uint_as_float(r[0].x), __uint_as_float(r[0].y), __uint_as_float(r[0].z), 0.f};
+                f32x4 v = {__uint_as_float(r[0].x), __uint_as_float(r[0].y), __uint_as_float(r[0].z), 0.f};
+                v *= a.att_scale;
                 amax = sat_amax4(amax, v);
                 unsigned p0, q0, p1, q1;
                 h2_split_pair(v.x, v.y, p0, q0);
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(512, 4) void rbfuse32_kernel(RbFuse32Dev a, int tot
 hipError_t launch_rbfuse32(hipStream_t s, const RbFuse32Args &h)
 {
     if (h.H != 32 || h.W != 32 || h.N <= 0) return hipErrorInvalidValue;
-    RbFuse32Dev a{h.x, h.x_stride, h.w0, h.w2, h.wsc, h.s0, h.s2, h.out, h.out_stride, h.out_f32, h.sat, h.q, h.bt, h.dire, h.att_layer};
+    RbFuse32Dev a{h.x, h.x_stride, h.w0, h.w2, h.wsc, h.s0, h.s2, h.out, h.out_stride, h.out_f32, h.sat, h.q, h.bt, h.dire, h.att_layer, h.att_scale};
     const int total = h.N * 4;
     const unsigned grid = (unsigned)(total < RF_GRID ? total : RF_GRID);       // persistent: two workgroups per CU, each a contiguous run of tiles
     if (!h.x) {

@@ -207,15 +207,17 @@ def trained_like_raw(comp, qp, weight_dir=None):
     return out
 
 
-def trained_like_msbd_weights(comp, qp, trunk_gain=1.0, gate_gain=1.0, weight_dir=None):
-    """Trained-like MTT-net weights (see the block comment above).  trunk_gain / gate_gain must be powers of two."""
-    for g in (trunk_gain, gate_gain):
+def trained_like_msbd_weights(comp, qp, trunk_gain=1.0, gate_gain=1.0, att_gain=1.0, weight_dir=None):
+    """Trained-like MTT-net weights (see the block comment above).  trunk_gain / gate_gain / att_gain must be powers of two.
+    att_gain A multiplies the FIRST block of both attention trunks (left.0 and shortcut: everything inside the attention trunks x A, the
+    gates with it), undone in conv_B2 / conv_B3 like gate_gain."""
+    for g in (trunk_gain, gate_gain, att_gain):
         m, _ = np.frexp(float(g))
         if g <= 0 or m != 0.5:
             raise ValueError("trained_like_msbd_weights: gains must be powers of two (exact in fp32)")
     tab = _tl_scales()[comp][str(qp)]
     raw = trained_like_raw(comp, qp, weight_dir)
-    K, G = np.float32(trunk_gain), np.float32(gate_gain)
+    K, G, A = np.float32(trunk_gain), np.float32(gate_gain), np.float32(att_gain)
     out = {}
     for name, a in raw.items():
         t = tab[name]
@@ -225,10 +227,13 @@ def trained_like_msbd_weights(comp, qp, trunk_gain=1.0, gate_gain=1.0, weight_di
         elif name in ("trunk_Att1.1.left.2.weight", "trunk_Att1.1.shortcut.0.weight",
                       "trunk_Att2.1.left.2.weight", "trunk_Att2.1.shortcut.0.weight"):
             w = w * G
+        elif name in ("trunk_Att1.0.left.0.weight", "trunk_Att1.0.shortcut.0.weight",
+                      "trunk_Att2.0.left.0.weight", "trunk_Att2.0.shortcut.0.weight"):
+            w = w * A
         elif name == "conv_B1.weight":
             w = w / K
         elif name in ("conv_B2.weight", "conv_B3.weight"):
-            w = w / (K * G)
+            w = w / (K * G * A)
         out[name] = np.ascontiguousarray(w, dtype=np.float32)
     return out
 

@@ -118,20 +118,21 @@ def test_trained_like_512_fresh_blocks_vs_oracle(eng, comp, qp):
 
 
 @pytest.mark.parametrize("comp,qp", [("Luma", 22), ("Chroma", 27)])
-@pytest.mark.parametrize("gains", [(64.0, 1.0), (1.0, 16.0), (64.0, 16.0), (1.0, 1024.0), (4096.0, 64.0), (65536.0, 256.0)])
+@pytest.mark.parametrize("gains", [(64.0, 1.0), (1.0, 16.0), (64.0, 16.0), (1.0, 1024.0), (4096.0, 64.0), (65536.0, 256.0), (1.0, 1.0, 2.0 ** 18), (256.0, 4.0, 2.0 ** 14)])
 def test_trained_like_stress_gains_stay_on_the_default_datapath(eng, comp, qp, gains):
     """trunk_gain K / gate_gain G are exact powers of two that the heads undo (synth.py): the reference's logits do not change (pinned
     while the goldens were generated), but the trunks now run at K x 1e3 and the gated products at K x G x 1e4 - far outside fp16.
     The default datapath must still deliver the golden logits, and must do so WITHOUT falling back to the 2.8x slower fp32 re-run:
     the per-segment power-of-two activation scales chosen when the net is first used absorb the range (include/pmp.h)."""
     g1, g2b = golden("g1_qt.npz"), golden("g2b_msbd_trained_like.npz")
-    K, G = gains
-    _load_tl(eng, comp, qp, trunk_gain=K, gate_gain=G)
+    K, G = gains[:2]
+    A = gains[2] if len(gains) > 2 else 1.0      # att_gain: the attention trunks themselves (segments 1 and 3) at A x their range
+    _load_tl(eng, comp, qp, trunk_gain=K, gate_gain=G, att_gain=A)
     eng.clear_saturation()
     qt, bt, dire = eng.inference_pre_QBD(comp, qp, g1["block_y"], g1["block_u"], g1["block_v"])
     err = _golden_err(bt, dire, g2b, comp, qp)
-    print("trained-like %s QP%d K=%g G=%g %s: err %.2e reruns %d" % (comp, qp, K, G, eng.get_precision(), err, eng.saturation_reruns()))
-    assert err < TOL, "%s QP%d K=%g G=%g off by %g" % (comp, qp, K, G, err)
+    print("trained-like %s QP%d K=%g G=%g A=%g %s: err %.2e reruns %d" % (comp, qp, K, G, A, eng.get_precision(), err, eng.saturation_reruns()))
+    assert err < TOL, "%s QP%d K=%g G=%g A=%g off by %g" % (comp, qp, K, G, A, err)
     assert eng.saturation_reruns() == 0, "the range guard fell back to fp32 (%d re-runs)" % eng.saturation_reruns()
 
 
@@ -154,7 +155,7 @@ def test_activation_scales_report():
             names = [t[0] for t in base["tensors"]]
             assert len(names) == 49 and names[0] == "stem" and names[1] == "trunk_M1.0.t" and names[-1] == "trunk_B3.2"
             assert [t[1] for t in base["tensors"] if t[0] in ("trunk_Att1.1", "trunk_Att2.1")] == [2, 4]   # the gated outputs open segments 2 and 4
-            assert 1e3 < base["seg_amax"][0] < 1e5 and base["exps"][1] == 0 and base["exps"][3] == 0
+            assert 1e3 < base["seg_amax"][0] < 1e5 and base["exps"][1] == 0 and base["exps"][3] == 0      # gates of O(10..200): no scale needed
             assert all(0 <= x <= 8 for x in base["exps"])
             print("activation scales %s QP%d: exps %s, segment maxima %s" % (comp, qp, base["exps"], ["%.3g" % m for m in base["seg_amax"]]))
             e.load(comp, qp, msbd_weights=synth.trained_like_msbd_weights(comp, qp, trunk_gain=64.0, gate_gain=16.0))
@@ -164,7 +165,7 @@ def test_activation_scales_report():
             for sg in (2, 4):
                 assert np.isclose(st["seg_amax"][sg], 1024.0 * base["seg_amax"][sg], rtol=1e-6)
                 assert st["seg_amax"][sg] * 2.0 ** -st["exps"][sg] <= 4096.0
-            for sg in (0, 2, 4):                              # the smallest exponent >= 0 that brings the segment's maximum to 2^12 or below
+            for sg in range(5):                               # the smallest exponent >= 0 that brings the segment's maximum to 2^12 or below
                 assert st["exps"][sg] == max(0, int(np.ceil(np.log2(st["seg_amax"][sg] / 4096.0)))), (sg, st)
             assert st["exps"][0] == base["exps"][0] + 6 or base["seg_amax"][0] <= 4096
     finally:

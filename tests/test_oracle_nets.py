@@ -89,7 +89,7 @@ def test_msbd_net_trained_like_weights(comp, qp):
     taps = {}
     with torch.no_grad():
         o = O.msbd_forward(wbd, x, q, luma, taps=taps)
-        o2 = O.msbd_forward(synth.trained_like_msbd_weights(comp, qp, trunk_gain=64.0, gate_gain=16.0), x, q, luma)
+        o2 = O.msbd_forward(synth.trained_like_msbd_weights(comp, qp, trunk_gain=64.0, gate_gain=16.0, att_gain=1024.0), x, q, luma)
     for i in range(3):
         assert np.abs(o[i].numpy() - g2b["out%d_%s_%d" % (i, comp, qp)]).max() < TOL
         assert torch.equal(o[i], o2[i])
