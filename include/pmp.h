@@ -135,7 +135,8 @@ int pmp_get_precision(const pmp_ctx *ctx);
  * over 32 built-in calibration blocks (flat, checkerboards, stripes, edges, white noise, smooth random content) on the fp32 MFMA
  * datapath records the largest |value| of every MTT tensor, and a segment whose maximum exceeds 2^12 gets the exponent that brings it
  * there (16x headroom below 65504 for content harsher than the calibration set; the attention trunks take theirs where their input is
- * built from the logits).
+ * built from the logits, capped at 2^-6: that input is O(1) and must stay out of fp16's subnormals - an attention trunk that needs more
+ * falls to the range guard).
  * Deterministic: same weights, same exponents, on every context and rank.  Exponents of zero - the synthetic uniform MTT weights, any
  * net whose activations stay below 4096 - leave the arithmetic exactly as it was.  That first use synchronises the stream once.
  * pmp_debug_activation_report (below) returns the exponents and the recorded maxima. */

@@ -140,6 +140,7 @@ static int run_graph(pmp_ctx *c, F &&fwd)
 // white, 1- and 2-pixel checkerboards, stripes, step edges, white noise, and smooth random content of three grain sizes (the kind
 // recipe R makes).  Deterministic (a 64-bit LCG), so every context, rank and run derives the same exponents from the same weights.
 constexpr int PMP_CAL_BLOCKS = 32;
+constexpr int PMP_CAL_ATT_MAX_EXP = 6;      // largest exponent of an attention segment (its input, built from O(1) logits, must stay out of fp16's subnormals)
 constexpr int PMP_CAL_PASS = 4;             // blocks per calibration pass
 constexpr int PMP_CAL_TARGET_EXP = 12;      // a segment whose calibration maximum exceeds 2^12 is scaled down to it: 16x headroom to 65504
 
@@ -251,6 +252,10 @@ static int calibrate_mtt(pmp_ctx *c, bool luma, NetWeights &wq, NetWeights &wb)
         if (!(m == m) || std::isinf(m)) continue;
         int ex = 0;
         while (ex < 60 && m > std::ldexp(1.f, PMP_CAL_TARGET_EXP + ex)) ++ex;
+        // An attention segment BEGINS with its smallest tensor - three channels of logits, O(1) - and one exponent serves the whole segment:
+        // beyond 2^-6 that input would sink into fp16's subnormals (measured: a 2^18 gain inside an attention trunk, fully absorbed, cost
+        // 1e-2 on the logits).  Capped there; a trunk that still leaves the range raises the flag and the call re-runs on fp32.
+        if ((sg == 1 || sg == 3) && ex > PMP_CAL_ATT_MAX_EXP) ex = PMP_CAL_ATT_MAX_EXP;
         exps[sg] = ex;
     }
     if ((rc = set_activation_scales(c, wb, exps)) != PMP_OK) return rc;
