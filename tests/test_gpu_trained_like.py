@@ -76,10 +76,10 @@ def _oracle(comp, qp, n):
 
 
 @pytest.mark.parametrize("comp,qp", [("Luma", 22), ("Luma", 37), ("Chroma", 27), ("Chroma", 37)])
-def test_trained_like_512_fresh_blocks_vs_oracle(eng, comp, qp):
-    """512 fresh blocks (flat, saturated, white-noise and checkerboard blocks included) against the torch oracle holding the same
+def test_trained_like_fresh_blocks_vs_oracle(eng, comp, qp):
+    """320 fresh blocks (flat, saturated, white-noise and checkerboard blocks included) against the torch oracle holding the same
     tensors; the record of what the guard did rides along."""
-    y, u, v, oq, obt, odire = _oracle(comp, qp, 512)
+    y, u, v, oq, obt, odire = _oracle(comp, qp, 320)
     _load_tl(eng, comp, qp)
     eng.clear_saturation()
     qt, bt, dire = eng.inference_pre_QBD(comp, qp, y, u, v)
