@@ -8,10 +8,11 @@ out = {}
 import os
 if os.path.isfile("profiles/pmc_traffic.json"):
     out = json.load(open("profiles/pmc_traffic.json"))
-for k, v in src.items():
+only = sys.argv[3] if len(sys.argv) > 3 else None      # round 5: an f16x3 run also holds a few tiny fp32 launches (the activation-scale calibration):
+for k, v in src.items():                                # python tools/make_traffic.py <pmc.json> <blocks per launch> f16x3 updates that entry alone
     mode = "fp32" if k.startswith("conv_mfma_kernel<3, 3, 4") else ("bf16x6" if k.startswith("conv_x6_kernel<3, 3, 4") else
                                                                       ("f16x3" if k.startswith(("conv_h2_kernel<3, 3, 4, sc=false", "conv_h2_kernel<3, 3, 4, sc=0")) else None))
-    if mode and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+    if mode and (only is None or mode == only) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         out["conv_mfma_3x3_c64:" + mode] = round((2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0)
         out["_blocks_per_launch:" + mode] = int(sys.argv[2]) if len(sys.argv) > 2 else 4096   # blocks per launch of the profiled run (bench.py scales)
         out["_detail:" + mode] = {"kernel": k, "FETCH_SIZE_KB": v["FETCH_SIZE"], "WRITE_SIZE_KB": v["WRITE_SIZE"],
