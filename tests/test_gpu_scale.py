@@ -85,6 +85,14 @@ def test_bench_world8_rehearsal():
     assert len(m["ms_per_step_by_rank"]) == 8 and all(t > 0 for t in m["ms_per_step_by_rank"]) and len(m["gather_ms_by_rank"]) == 8
     assert "preflight ok: 8 ranks" in r.stderr
     assert d["value"] > 0 and abs(d["value"] - 128 / 4.0 / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]
+    # round 5: every rank's own clock / socket power (sysfs hwmon, sampled by a host thread during the timed region) and workspace, so that a
+    # sub-linear 8-GPU curve can be read from the JSON alone: node power (clocks below the 1-GPU line's), the exchange, or one slow rank
+    for key in ("sclk_mhz_mean_by_rank", "sclk_mhz_min_by_rank", "power_w_mean_by_rank", "power_w_max_by_rank", "workspace_bytes_by_rank"):
+        assert len(m[key]) == 8, key
+    assert all(w > 0 for w in m["workspace_bytes_by_rank"])
+    assert all(c is not None and 100 < c < 3000 for c in m["sclk_mhz_mean_by_rank"]), m["sclk_mhz_mean_by_rank"]
+    assert all(p is not None and 50 < p < 2000 for p in m["power_w_mean_by_rank"]), m["power_w_mean_by_rank"]
+    assert d["sensors"]["samples"] >= 1 and d["sensors"]["source"].startswith("sysfs hwmon")
 
 
 def test_bench_under_torch_distributed_run():
