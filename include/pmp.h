@@ -69,7 +69,7 @@ int pmp_destroy(pmp_ctx *ctx);
 
 /* pmp_destroy parks the context's activation workspace (up to 10 GB) for the next context created on the same device instead of
  * freeing it: a large hipMalloc right after a hipFree of that size stalls for 0.5-1.4 s now and then on MI355X (the freed memory is
- * still being cleared).  One parked buffer per device; pmp_trim() returns parked memory to the driver - a host that destroys its
+ * still being cleared).  Up to two parked buffers per device (a context in overlap mode owns two workspaces); pmp_trim() returns parked memory to the driver - a host that destroys its
  * context to hand the VRAM to another library calls it right after pmp_destroy (or runs with PMP_PARK_WORKSPACE=0 in the
  * environment: nothing is parked then).  pmp_trim leaves the calling thread's current device as it is. */
 int pmp_trim(void);

@@ -33,7 +33,9 @@ int hip_fail(pmp_ctx *c, hipError_t e, const char *what)
 // for a host that destroys its context to hand the VRAM to another library and cannot call pmp_trim).
 namespace {
 std::mutex g_park_mutex;
-std::map<int, DevBuf> g_parked;   // device -> buffer
+constexpr int PARK_SLOTS = 2;     // a context in overlap mode owns two workspaces (ws, ws2): both are parked (round 5; one slot until then)
+struct Parked { DevBuf b[PARK_SLOTS]; };
+std::map<int, Parked> g_parked;   // device -> buffers
 }  // namespace
 
 static void park_workspace(int device, DevBuf &b)
@@ -42,9 +44,14 @@ static void park_workspace(int device, DevBuf &b)
     const char *env = std::getenv("PMP_PARK_WORKSPACE");
     if (env && env[0] == '0' && !env[1]) { hipFree(b.p); b = DevBuf(); return; }
     std::lock_guard<std::mutex> lk(g_park_mutex);
-    DevBuf &slot = g_parked[device];
-    if (slot.cap >= b.cap) { hipFree(b.p); }
-    else { if (slot.p) hipFree(slot.p); slot = b; }
+    Parked &pk = g_parked[device];
+    int victim = 0;                                   // an empty slot, else the smallest parked buffer
+    for (int i = 0; i < PARK_SLOTS; ++i) {
+        if (!pk.b[i].p) { victim = i; break; }
+        if (pk.b[i].cap < pk.b[victim].cap) victim = i;
+    }
+    if (pk.b[victim].p && pk.b[victim].cap >= b.cap) { hipFree(b.p); }         // everything parked is at least as large: drop the newcomer
+    else { if (pk.b[victim].p) hipFree(pk.b[victim].p); pk.b[victim] = b; }
     b = DevBuf();
 }
 
@@ -52,15 +59,19 @@ static bool take_parked(int device, size_t bytes, DevBuf &out)
 {
     std::lock_guard<std::mutex> lk(g_park_mutex);
     auto it = g_parked.find(device);
-    if (it == g_parked.end() || it->second.cap < bytes) return false;
-    out = it->second;
-    g_parked.erase(it);
+    if (it == g_parked.end()) return false;
+    int best = -1;                                    // the smallest parked buffer that is large enough
+    for (int i = 0; i < PARK_SLOTS; ++i)
+        if (it->second.b[i].p && it->second.b[i].cap >= bytes && (best < 0 || it->second.b[i].cap < it->second.b[best].cap)) best = i;
+    if (best < 0) return false;
+    out = it->second.b[best];
+    it->second.b[best] = DevBuf();
     return true;
 }
 
 static int ensure(pmp_ctx *c, DevBuf &b, size_t bytes)
 {
-    if (&b == &c->ws && bytes > b.cap && bytes >= ((size_t)64 << 20)) {   // a large activation workspace: a parked one of a destroyed context first (small ones are cheap to allocate and stay small)
+    if ((&b == &c->ws || &b == &c->ws2) && bytes > b.cap && bytes >= ((size_t)64 << 20)) {   // a large activation workspace: a parked one of a destroyed context first (small ones are cheap to allocate and stay small)
         DevBuf got;
         if (take_parked(c->device, bytes, got)) {
             if (b.p) hipFree(b.p);
@@ -556,6 +567,7 @@ int pmp_destroy(pmp_ctx *c)
     for (auto &kv : c->nets) free_net_weights(kv.second);
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
     park_workspace(c->device, c->ws);
+    park_workspace(c->device, c->ws2);
     DevBuf *bufs[] = {&c->ws, &c->ws2, &c->d_in[0], &c->d_in[1], &c->d_in[2], &c->d_logit[0], &c->d_logit[1], &c->d_logit[2],
                       &c->d_out[0], &c->d_out[1], &c->d_out[2], &c->d_out[3], &c->d_frames[0], &c->d_frames[1], &c->d_frames[2]};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
@@ -572,7 +584,8 @@ int pmp_destroy(pmp_ctx *c)
 int pmp_trim(void)
 {
     std::lock_guard<std::mutex> lk(g_park_mutex);
-    for (auto &kv : g_parked) if (kv.second.p) hipFree(kv.second.p);   // hipFree needs no current device: the caller's stays as it is
+    for (auto &kv : g_parked)
+        for (DevBuf &b : kv.second.b) if (b.p) hipFree(b.p);          // hipFree needs no current device: the caller's stays as it is
     g_parked.clear();
     return PMP_OK;
 }
