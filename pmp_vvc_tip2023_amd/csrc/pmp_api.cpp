@@ -152,7 +152,7 @@ static int run_graph(pmp_ctx *c, F &&fwd)
 // recipe R makes).  Deterministic (a 64-bit LCG), so every context, rank and run derives the same exponents from the same weights.
 constexpr int PMP_CAL_BLOCKS = 32;
 constexpr int PMP_CAL_ATT_MAX_EXP = 6;      // largest exponent of an attention segment (its input, built from O(1) logits, must stay out of fp16's subnormals)
-constexpr int PMP_CAL_PASS = 4;             // blocks per calibration pass
+constexpr int PMP_CAL_PASS = 16;            // blocks per calibration pass (its private workspace: 44 MB)
 constexpr int PMP_CAL_TARGET_EXP = 12;      // a segment whose calibration maximum exceeds 2^12 is scaled down to it: 16x headroom to 65504
 
 static void make_calibration_blocks(std::vector<uint8_t> &y, std::vector<uint8_t> &u, std::vector<uint8_t> &v)
@@ -219,6 +219,20 @@ static int calibrate_mtt(pmp_ctx *c, bool luma, NetWeights &wq, NetWeights &wb)
     if ((rc = ensure(c, c->d_calbuf, o_dr + (size_t)n * 768 * 4)) != PMP_OK) return rc;
     hipError_t e = hipSuccess;
     if (!c->d_cal) e = hipMalloc((void **)&c->d_cal, PMP_CAL_SLOTS * sizeof(unsigned));
+    if (e == hipSuccess && !c->cal_stream) e = hipStreamCreateWithFlags(&c->cal_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) return hip_fail(c, e, "calibration: stream");
+    // Its OWN stream and workspace: the calibration depends on nothing the context's stream is doing (weights are uploaded synchronously,
+    // its blocks and logits are its own), so it runs beside the passes in flight instead of behind them - a driver that loads the next
+    // (component, QP) while the GPU works on this one (pmp_load_weights calibrates a pair as soon as it is complete) pays host time only.
+    // Round 5's first form ran it on the context's stream inside the first inference call: 8 x 25 ms of exposed serialisation per 8-file job.
+    hipStream_t user_stream = c->stream;
+    const size_t user_need = c->ws_need;
+    c->stream = c->cal_stream;
+    std::swap(c->ws, c->ws_cal);
+    struct Restore {
+        pmp_ctx *c; hipStream_t s; size_t need;
+        ~Restore() { c->stream = s; std::swap(c->ws, c->ws_cal); c->ws_need = need; c->cal_on = 0; }
+    } restore{c, user_stream, user_need};
     char *base = static_cast<char *>(c->d_calbuf.p);
     if (e == hipSuccess) e = hipMemcpyAsync(base, hy.data(), hy.size(), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(base + o_u, hu.data(), hu.size(), hipMemcpyHostToDevice, c->stream);
@@ -229,7 +243,7 @@ static int calibrate_mtt(pmp_ctx *c, bool luma, NetWeights &wq, NetWeights &wb)
     float *dq = (float *)(base + o_q), *dbt = (float *)(base + o_bt), *ddr = (float *)(base + o_dr);
     const int saved = c->precision;
     c->precision = PMP_PRECISION_F32;
-    // passes of PMP_CAL_PASS blocks: the calibration must not be what sizes the activation workspace (a 4-block call stays in 11 MB,
+    // passes of PMP_CAL_PASS blocks in the private workspace (the context's own stays what its calls need: a 4-block call in 11 MB,
     // include/pmp.h); every pass folds into the same slots, so the log is that of the first pass
     rc = PMP_OK;
     for (int o = 0; o < n && rc == PMP_OK; o += PMP_CAL_PASS) {
@@ -574,6 +588,8 @@ int pmp_destroy(pmp_ctx *c)
     if (c->d_sat) hipFree(c->d_sat);
     if (c->d_cal) hipFree(c->d_cal);
     if (c->d_calbuf.p) hipFree(c->d_calbuf.p);
+    if (c->ws_cal.p) hipFree(c->ws_cal.p);
+    if (c->cal_stream) hipStreamDestroy(c->cal_stream);
     if (c->h_sat) hipHostFree(c->h_sat);
     if (c->stream2) hipStreamDestroy(c->stream2);
     hipStreamDestroy(c->own_stream);
@@ -666,6 +682,18 @@ int pmp_clear_saturation(pmp_ctx *c)
     return rc;
 }
 
+// A (QT, MTT) pair that has just become complete is calibrated at once (f16x3 activation scales, on the calibration's own stream): at
+// LOAD time, where a pipelined host hides it, not inside its first inference call.  The lazy check in infer_passes stays for pairs loaded
+// under another datapath.
+static int calibrate_if_ready(pmp_ctx *c, int net_id, int qp)
+{
+    if (c->precision != PMP_PRECISION_F16X3 || !c->act_scales) return PMP_OK;
+    const bool luma = net_id == PMP_NET_LUMA_Q || net_id == PMP_NET_LUMA_MSBD;
+    NetWeights *wq = find_net(c, luma ? PMP_NET_LUMA_Q : PMP_NET_CHROMA_Q, qp), *wb = find_net(c, luma ? PMP_NET_LUMA_MSBD : PMP_NET_CHROMA_MSBD, qp);
+    if (!wq || !wb || wb->calibrated) return PMP_OK;
+    return calibrate_mtt(c, luma, *wq, *wb);
+}
+
 int pmp_load_weights(pmp_ctx *c, int net_id, int qp, const float *blob, const pmp_tensor_desc *descs, int ndesc)
 {
     CHECK_CTX(c);
@@ -674,7 +702,8 @@ int pmp_load_weights(pmp_ctx *c, int net_id, int qp, const float *blob, const pm
     // (component, QP) while the GPU works on this one
     int rc = pmp_has_weights(c, net_id, qp) ? settle(c) : PMP_OK;
     if (rc != PMP_OK) return rc;
-    return load_net_weights(c, net_id, qp, blob, descs, ndesc);
+    if ((rc = load_net_weights(c, net_id, qp, blob, descs, ndesc)) != PMP_OK) return rc;
+    return calibrate_if_ready(c, net_id, qp);
 }
 
 int pmp_load_weights_file(pmp_ctx *c, int net_id, int qp, const char *path)
@@ -694,7 +723,8 @@ int pmp_load_weights_file(pmp_ctx *c, int net_id, int qp, const char *path)
         descs[i].offset = wf.tensors[i].offset;
     }
     if (pmp_has_weights(c, net_id, qp) && (rc = settle(c)) != PMP_OK) return rc;   // see pmp_load_weights
-    return load_net_weights(c, net_id, qp, wf.payload.data(), descs.data(), (int)descs.size());
+    if ((rc = load_net_weights(c, net_id, qp, wf.payload.data(), descs.data(), (int)descs.size())) != PMP_OK) return rc;
+    return calibrate_if_ready(c, net_id, qp);
 }
 
 int pmp_has_weights(const pmp_ctx *c, int net_id, int qp)

@@ -158,6 +158,8 @@ struct pmp_ctx {
     unsigned *d_cal = nullptr;             // PMP_CAL_SLOTS device words
     std::vector<std::pair<std::string, int>> cal_log;
     pmp::DevBuf d_calbuf;                  // calibration blocks and their logits
+    hipStream_t cal_stream = nullptr;      // calibration runs on its own stream and workspace: it neither waits for the passes in flight on the
+    pmp::DevBuf ws_cal;                    // context's stream nor touches their workspace (created on first use; 44 MB for 16-block fp32 passes)
     // kernel-class timing
     uint32_t kmask = 0;
     std::vector<pmp::KTimeRec> krec[pmp::K_NCLASS];
