@@ -724,6 +724,14 @@ int pmp_load_weights_file(pmp_ctx *c, int net_id, int qp, const char *path)
     }
     if (pmp_has_weights(c, net_id, qp) && (rc = settle(c)) != PMP_OK) return rc;   // see pmp_load_weights
     if ((rc = load_net_weights(c, net_id, qp, wf.payload.data(), descs.data(), (int)descs.size())) != PMP_OK) return rc;
+    if (wf.act_exp.size() == 5 && (net_id == PMP_NET_LUMA_MSBD || net_id == PMP_NET_CHROMA_MSBD)) {
+        // the file carries its activation-scale exponents (the conversion tool calibrated once): nothing to run here
+        NetWeights *nw = find_net(c, net_id, qp);
+        if ((rc = set_activation_scales(c, *nw, wf.act_exp.data())) != PMP_OK) return rc;
+        nw->calibrated = true;
+        nw->cal_names.clear(); nw->cal_seg.clear(); nw->cal_amax.clear();
+        return PMP_OK;
+    }
     return calibrate_if_ready(c, net_id, qp);
 }
 

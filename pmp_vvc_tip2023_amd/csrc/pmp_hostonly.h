@@ -26,7 +26,8 @@ std::vector<float> pack_plain(const float *w, int cout, int cin, int kh, int kw)
 
 // pmpw_file.cpp: the product's weight container (.pmpw)
 struct WeightTensor { std::string name; int ndim = 0; int shape[4] = {0, 0, 0, 0}; long long offset = 0; };
-struct WeightFile { std::string net; int qp = -1; std::vector<WeightTensor> tensors; std::vector<float> payload; };
+struct WeightFile { std::string net; int qp = -1; std::vector<WeightTensor> tensors; std::vector<float> payload;
+                    std::vector<int> act_exp; };   // optional manifest key "act_exp": the five f16x3 activation-scale exponents of an MTT net (include/pmp.h)
 int read_pmpw(const char *path, WeightFile &wf);
 int net_id_of(const std::string &net);
 

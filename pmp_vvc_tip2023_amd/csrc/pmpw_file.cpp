@@ -1,7 +1,8 @@
 // pmpw_file.cpp — reader of the product's weight container (.pmpw, written by pmp_vvc_tip2023_amd/weights.py):
 //
 //     "PMPW1\n" | u32 little-endian JSON length | JSON manifest | raw little-endian float32 payload
-//     manifest = {"net": "Luma_Q", "qp": 22, "source": "...", "tensors": [{"name": "...", "shape": [..], "offset": N}, ...]}
+//     manifest = {"net": "Luma_Q", "qp": 22, "source": "...", "tensors": [{"name": "...", "shape": [..], "offset": N}, ...]
+//                 [, "act_exp": [e0, e1, e2, e3, e4]]}      (MTT nets: f16x3 activation-scale exponents, then no calibration at load)
 //
 // so that a host without Python (the in-process VTM hook) can feed pmp_load_weights.  Counterpart of
 // load_pretrain_model (Inference_QBD.py:28-46).  Pure host code (no HIP): part of the sanitizer test library too.
@@ -103,6 +104,20 @@ int read_pmpw(const char *path, WeightFile &wf)
             if (!s.str(key) || !s.lit(':')) return bad("bad key");
             if (key == "net") { if (!s.str(wf.net)) return bad("net is not a string"); }
             else if (key == "qp") { long long v; if (!s.integer(v)) return bad("qp is not an integer"); wf.qp = (int)v; }
+            else if (key == "act_exp") {   // optional: [e0, e1, e2, e3, e4], written by the conversion tool after a calibration on the target GPU
+                if (!s.lit('[')) return bad("act_exp is not an array");
+                if (!s.lit(']')) {
+                    for (;;) {
+                        long long v;
+                        if (!s.integer(v) || v < 0 || v > 60 || wf.act_exp.size() >= 5) return bad("act_exp entry (five integers 0..60)");
+                        wf.act_exp.push_back((int)v);
+                        if (s.lit(',')) continue;
+                        if (!s.lit(']')) return bad("act_exp end");
+                        break;
+                    }
+                }
+                if (wf.act_exp.size() != 5) return bad("act_exp needs five entries");
+            }
             else if (key == "tensors") {
                 have_tensors = true;
                 if (!s.lit('[')) return bad("tensors is not an array");

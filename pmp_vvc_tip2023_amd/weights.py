@@ -5,7 +5,7 @@ prefixes (trained_models/*.pkl; loader Inference_QBD.py:28-46).  The product's o
 
     b"PMPW1\\n" | u32 little-endian JSON length | JSON manifest | raw little-endian float32 payload
 
-manifest = {"net": "Luma_Q", "qp": 22, "source": ..., "tensors": [{"name", "shape", "offset"(floats)}]}.
+manifest = {"net": "Luma_Q", "qp": 22, "source": ..., "tensors": [{"name", "shape", "offset"(floats)}][, "act_exp": [5 ints]]}.
 Tensor names/shapes are the reference's state_dict names with `module.` stripped (OIHW convs, 1-D biases).
 `.pmpw` needs only numpy; `.pkl` import needs torch (PyTorch is used for weight loading only).
 """
@@ -20,14 +20,20 @@ NETS = ("Luma_Q", "Luma_MSBD", "Chroma_Q", "Chroma_MSBD")
 QPS = (22, 27, 32, 37)
 
 
-def save_pmpw(path, net, qp, tensors, source=""):
-    """tensors: ordered {name: float32 ndarray}."""
+def save_pmpw(path, net, qp, tensors, source="", act_exp=None):
+    """tensors: ordered {name: float32 ndarray}.  act_exp (MTT nets, optional): the five f16x3 activation-scale exponents a calibration on
+    the target GPU chose (Engine.activation_report(...)["exps"]); a file that carries them is loaded without a calibration pass."""
     entries, off = [], 0
     for name, a in tensors.items():
         a = np.ascontiguousarray(a, dtype="<f4")
         entries.append({"name": name, "shape": list(a.shape), "offset": off})
         off += a.size
-    man = json.dumps({"net": net, "qp": int(qp), "source": source, "tensors": entries}).encode()
+    man = {"net": net, "qp": int(qp), "source": source, "tensors": entries}
+    if act_exp is not None:
+        if len(act_exp) != 5 or any(int(e) < 0 or int(e) > 60 for e in act_exp):
+            raise ValueError("act_exp: five integers 0..60")
+        man["act_exp"] = [int(e) for e in act_exp]
+    man = json.dumps(man).encode()
     with open(path, "wb") as f:
         f.write(MAGIC)
         f.write(struct.pack("<I", len(man)))

@@ -3,7 +3,7 @@ i.e. the whole-job rate including file I/O, H2D, D2H, text formatting and file w
 path only).  Prints the main thread's wall time per stage (inference_qbd.Stages), the pure-GPU time of the same passes for
 comparison, and the N-rank critical path those stages project to with sharded emission.
 
-Usage: python tools/driver_bench.py [W H FRAMES] [--emit sharded|gather] [--seqs K] [--abOverlap 1]      default 1920 1080 8"""
+Usage: python tools/driver_bench.py [W H FRAMES] [--emit sharded|gather] [--seqs K] [--abOverlap 1] [--noManifestExps 1]      default 1920 1080 8"""
 import os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -38,6 +38,12 @@ for comp in ("Luma", "Chroma"):
     for qp in (22, 27, 32, 37):
         shutil.copy(os.path.join(Wt.default_weight_dir(), "%s_Q_%d.pmpw" % (comp, qp)), models)
         Wt.save_pmpw(os.path.join(models, "%s_BD_%d.pmpw" % (comp, qp)), comp + "_MSBD", qp, synth.synth_msbd_weights(comp, qp), source="synthetic(seed=%d)" % qp)
+# ... and, as a converted model directory has them (tools/calibrate_pmpw.py), the MTT files carry their activation-scale exponents, so
+# that loading them runs no calibration pass (--noManifestExps 1: leave them out, every job calibrates its eight nets while loading)
+if opt.get("--noManifestExps") != "1":
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import calibrate_pmpw
+    calibrate_pmpw.calibrate_dir(models, 0, log=lambda *a: None)
 args = ["--jobID", "b", "--inputDir", inp, "--outDir", out, "--seqTable", "table.txt", "--cfgDir", cfg, "--ssRatio", "1",
         "--startSeqID", "0", "--seqNum", str(nseq), "--modelDir", models, "--emit", emit_mode]
 D.main(args)            # warm-up (weights, workspace, first-touch, page cache)
