@@ -138,7 +138,12 @@ int pmp_get_precision(const pmp_ctx *ctx);
  * built from the logits, capped at 2^-6: that input is O(1) and must stay out of fp16's subnormals - an attention trunk that needs more
  * falls to the range guard).
  * Deterministic: same weights, same exponents, on every context and rank.  Exponents of zero - the synthetic uniform MTT weights, any
- * net whose activations stay below 4096 - leave the arithmetic exactly as it was.  That first use synchronises the stream once.
+ * net whose activations stay below 4096 - leave the arithmetic exactly as it was.
+ * WHEN: as soon as both nets of a (component, QP) are loaded while the context is on the f16x3 datapath - inside the pmp_load_weights*
+ * call that completes the pair (≈ 20 ms of host time; the pass runs on a private stream and a private 44 MB workspace, beside whatever the
+ * context's stream is doing) - or, for a pair loaded under another datapath, at its first f16x3 inference call.  NOT AT ALL for an MTT
+ * file whose .pmpw manifest carries "act_exp": [e0..e4] (tools/calibrate_pmpw.py writes them once per model directory): those exponents
+ * are taken as they are.
  * pmp_debug_activation_report (below) returns the exponents and the recorded maxima. */
 #define PMP_SAT_RERUN 0
 #define PMP_SAT_ERROR 1
