@@ -14,6 +14,7 @@ import torch
 TOL = 1e-3
 N = int(os.environ.get("PMP_CAMPAIGN_BLOCKS", "4096"))
 PRECISION = os.environ.get("PMP_CAMPAIGN_PRECISION", "f16x3")      # f16x3 (default datapath) | bf16x6 | fp32
+MTT_WEIGHTS = os.environ.get("PMP_CAMPAIGN_MTT", "synthetic")      # synthetic (uniform, seed = qp) | trained_like (synth.trained_like_msbd_weights, round 5)
 
 
 @pytest.fixture(scope="module")
@@ -36,11 +37,16 @@ def test_full_size_parity(eng, comp, qp):
     luma = comp == "Luma"
     y, u, v = synth.recipe_r_blocks(N, 5000 + qp + (11 if not luma else 0))
     wq, _ = W.load_net_weights(comp + "_Q", qp)
-    wbd, src = W.load_net_weights(comp + "_MSBD", qp, allow_synthetic=True)
+    if MTT_WEIGHTS == "trained_like":
+        wbd = synth.trained_like_msbd_weights(comp, qp)
+        eng.load(comp, qp, msbd_weights=wbd)
+        print("\n       trained-like MTT weights: activation exponents %s" % eng.activation_report(comp, qp)["exps"], flush=True)
+    else:
+        wbd, src = W.load_net_weights(comp + "_MSBD", qp, allow_synthetic=True)
     x = O.luma_input(y) if luma else O.chroma_input(y, u, v)
     oq, obt, od = O.infer_qbd(wq, wbd, x, luma, batch=64)
     hor, ver, q8, d8, qt, bt, dire = eng.infer_postprocess(comp, qp, y, u, v, want_logits=True)
-    assert not eng.saturated()
+    assert not eng.saturated() and eng.saturation_reruns() == 0
     err = (float(np.abs(qt - oq).max()), float(np.abs(bt - obt).max()), float(np.abs(dire - od).max()))
     strict = os.environ.get("PMP_CAMPAIGN_REPORT_ONLY", "0") != "1"       # report-only: print every figure below before judging (profiles/)
     assert max(err) < TOL or not strict, "%s QP%d logits off by %s" % (comp, qp, err)
