@@ -27,6 +27,10 @@ namespace {
 constexpr int RF_IW = 20, RF_TW = 18;                        // image widths: input (tile + 2 x 2), intermediate (tile + 2 x 1)
 constexpr int RF_IPLN = RF_IW * RF_IW * 32, RF_ISLOT = 2 * RF_IPLN;    // bytes per fp16 plane / per 16-channel group (both planes)
 constexpr int RF_TPLN = RF_TW * RF_TW * 32, RF_TSLOT = 2 * RF_TPLN;
+// Inside a plane: [channel half][pixel][8 channels = 16 B] - NOT the [pixel][32 B] of the launch kernels' halo tiles.  A 16-lane group of a
+// ds_read_b128 / ds_write_b128 then covers 256 contiguous bytes (64 banks, one pass); with 32 B between neighbouring pixels lanes i and i + 8
+// share their banks (PMC on the first forms of this kernel: 40 % of the LDS cycles were bank conflicts).
+constexpr int RF_IHH = RF_IW * RF_IW * 16, RF_THH = RF_TW * RF_TW * 16;  // bytes per channel half of a plane
 constexpr int RF_GRID = 512;                                 // persistent workgroups: 2 per CU x 256 CUs
 constexpr int RF_NT1 = (RF_TW * RF_TW + 15) / 16;            // 21 pixel columns-of-16 cover the 18x18 region of the first convolution
 
@@ -46,7 +50,7 @@ __device__ __forceinline__ constexpr int rf_step_off(int st, int half)
         cb = st / per;
         tap = 2 * ks + half < T ? 2 * ks + half : 2 * ks;
     }
-    return cb * SLOT + (T == 1 ? 0 : ((tap / 3) * IMW + tap % 3) * 32);
+    return cb * SLOT + (T == 1 ? 0 : ((tap / 3) * IMW + tap % 3) * 16);
 }
 
 template <int T, int CB>
@@ -57,7 +61,7 @@ struct RfSteps {
 };
 
 // One pass over CB source groups into KI accumulators of this wave (KI pixel columns-of-16 x ONE output group).  Item k's window origin
-// for this lane: pb[k] bytes inside a group plane (+ 16 for the upper 8 channels) if ISTR == 0, else pb[0] + k * ISTR (consecutive rows:
+// for this lane: pb[k] bytes inside a group plane (+ the half-plane size for the upper 8 channels) if ISTR == 0, else pb[0] + k * ISTR (consecutive rows:
 // the offsets become instruction immediates).  The LAST item is skipped unless `last` (wave-uniform: the 21 columns-of-16 of the first
 // convolution do not divide evenly among the waves).  wbase: the pass's weight stream at this wave's output group (uniform), wv: lane * 16.
 // Order per accumulator: x0*w1, x0*w0, x1*w0, K-step after K-step - the launch path's.
@@ -159,11 +163,11 @@ __global__ __launch_bounds__(512, 4) void rbfuse32_kernel(RbFuse32Dev a, int tot
 #pragma unroll
     for (int k = 0; k < KI1; ++k) {
         const int pix = (wsub + k * WPG) * 16 + xl, p = min(pix, RF_TW * RF_TW - 1), py = p / RF_TW, px = p - py * RF_TW;
-        pb1[k] = (py * RF_IW + px) * 32 + (g & 1) * 16;
+        pb1[k] = (py * RF_IW + px) * 16 + (g & 1) * RF_IHH;
         pyx1[k] = py | (px << 8) | ((pix < RF_TW * RF_TW) ? 1 << 16 : 0);
     }
     const int row0 = wsub * KI2;                                  // second convolution: this wave's KI2 consecutive rows
-    const int pb2[1] = {(row0 * RF_TW + xl) * 32 + (g & 1) * 16}, pbs[1] = {((row0 + 2) * RF_IW + xl + 2) * 32 + (g & 1) * 16};
+    const int pb2[1] = {(row0 * RF_TW + xl) * 16 + (g & 1) * RF_THH}, pbs[1] = {((row0 + 2) * RF_IW + xl + 2) * 16 + (g & 1) * RF_IHH};
     const unsigned ov = POOLF ? (unsigned)(((row0 >> 1) * (S / 2) + (xl >> 1)) * 64 + g * 16)
                               : (unsigned)(((row0 + (g & 1)) * S + xl) * 32 + 16 * (g >> 1));            // output byte offset inside (block, group, tile)
     const char *w0b = reinterpret_cast<const char *>(a.w0) + ct * 1024, *w2b = reinterpret_cast<const char *>(a.w2) + ct * 1024,
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(512, 4) void rbfuse32_kernel(RbFuse32Dev a, int tot
     auto stash = [&]() __attribute__((always_inline)) {
         if (tid >= NPX) return;
         const u32x4 z = {0u, 0u, 0u, 0u};
-        char *d = img + tid * 32;
+        char *d = img + tid * 16;
         if (ATT) {
             u32x4 lo = z, hi4 = z;
             if (fin) {
@@ -213,13 +217,13 @@ __global__ __launch_bounds__(512, 4) void rbfuse32_kernel(RbFuse32Dev a, int tot
                 lo.x = p0; lo.y = p1; hi4.x = q0; hi4.y = q1;
             }
             *reinterpret_cast<u32x4 *>(d) = lo;
-            *reinterpret_cast<u32x4 *>(d + 16) = z;
+            *reinterpret_cast<u32x4 *>(d + RF_IHH) = z;
             *reinterpret_cast<u32x4 *>(d + RF_IPLN) = hi4;
-            *reinterpret_cast<u32x4 *>(d + RF_IPLN + 16) = z;
+            *reinterpret_cast<u32x4 *>(d + RF_IPLN + RF_IHH) = z;
         } else {
 #pragma unroll
             for (int i = 0; i < NLD; ++i)
-                *reinterpret_cast<u32x4 *>(d + (i >> 2) * RF_ISLOT + ((i >> 1) & 1) * RF_IPLN + (i & 1) * 16) = fin ? r[i] : z;
+                *reinterpret_cast<u32x4 *>(d + (i >> 2) * RF_ISLOT + ((i >> 1) & 1) * RF_IPLN + (i & 1) * RF_IHH) = fin ? r[i] : z;
         }
     };
     fetch(t_begin);
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(512, 4) void rbfuse32_kernel(RbFuse32Dev a, int tot
                 unsigned p0, q0, p1, q1;
                 h2_split_pair(v.x, v.y, p0, q0);
                 h2_split_pair(v.z, v.w, p1, q1);
-                char *dp = timg + ct * RF_TSLOT + (py * RF_TW + px) * 32 + g * 8;
+                char *dp = timg + ct * RF_TSLOT + (g >> 1) * RF_THH + (py * RF_TW + px) * 16 + (g & 1) * 8;
                 *reinterpret_cast<u32x2_t *>(dp) = (u32x2_t){p0, p1};
                 *reinterpret_cast<u32x2_t *>(dp + RF_TPLN) = (u32x2_t){q0, q1};
             }
@@ -271,8 +275,8 @@ __global__ __launch_bounds__(512, 4) void rbfuse32_kernel(RbFuse32Dev a, int tot
         f32x4 acc[KI2];
 #pragma unroll
         for (int k = 0; k < KI2; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        rf_accumulate<9, NT, NT, KI2, RF_TW, RF_TSLOT, RF_TPLN, RF_TW * 32, 1>(timg, w2b, wvt, hi, pb2, true, acc);
-        rf_accumulate<1, CB_IN, NT, KI2, RF_IW, RF_ISLOT, RF_IPLN, RF_IW * 32, 1>(img, wsb, wvt, hi, pbs, true, acc);       // ResidualBlock, Model_QBD.py:33-38
+        rf_accumulate<9, NT, NT, KI2, RF_TW, RF_TSLOT, RF_TPLN, RF_TW * 16, 1>(timg, w2b, wvt, hi, pb2, true, acc);
+        rf_accumulate<1, CB_IN, NT, KI2, RF_IW, RF_ISLOT, RF_IPLN, RF_IW * 16, 1>(img, wsb, wvt, hi, pbs, true, acc);       // ResidualBlock, Model_QBD.py:33-38
 #pragma unroll
         for (int k = 0; k < KI2; ++k) {
             f32x4 v = acc[k] * a.s2;
