@@ -49,7 +49,7 @@ std::vector<unsigned short> pack_h2_wx(const float *w, int *scale_exp)
     return out;
 }
 
-const char *abl_version() { return "pmp-hip 0.4-abl (gfx950; f16x3 / bf16x6 split MFMA + fp32 MFMA; MEASUREMENT BUILD with timing-only kernels)"; }
+const char *abl_version() { return "pmp-hip 0.5-abl (gfx950; f16x3 / bf16x6 split MFMA + fp32 MFMA; MEASUREMENT BUILD with timing-only kernels)"; }
 
 void abl_on_create()
 {
