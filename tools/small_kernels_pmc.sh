@@ -1,5 +1,5 @@
 #!/bin/bash
-# Run ON THE GPU BOX: PMC passes (counters only) over a short bench.py run, summarised for the rbfuse32 kernels -> gpurun_out/pmc_rbfuse32/
+# Run ON THE GPU BOX: PMC passes (counters only) over a short bench.py run, summarised for the rbfuse32 kernels -> gpurun_out/pmc_rbfuse32/   (rbfuse32, chain16, stems, post-processing: the kernels next to the big convolutions)
 set -u
 OUT=$PWD/gpurun_out/pmc_rbfuse32
 mkdir -p $OUT
