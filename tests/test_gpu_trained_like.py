@@ -223,3 +223,29 @@ def test_manifest_exponents_skip_the_calibration(tmp_path):
         e2.close()
     for p, q in zip(a, b):
         assert np.array_equal(p, q)
+
+
+def test_calibrate_pmpw_tool_writes_the_exponents(tmp_path):
+    """tools/calibrate_pmpw.py on a model directory (real QT files + trained-like MTT files without exponents): every MTT file comes back
+    with "act_exp" in its manifest, equal to what a calibrating load reports, and with its tensors untouched."""
+    import shutil
+    import sys
+    from pmp_vvc_tip2023_amd import engine, synth, weights as W
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import calibrate_pmpw
+    for comp, qp in (("Luma", 22), ("Chroma", 37)):
+        shutil.copy(os.path.join(W.default_weight_dir(), "%s_Q_%d.pmpw" % (comp, qp)), tmp_path)
+        W.save_pmpw(str(tmp_path / ("%s_BD_%d.pmpw" % (comp, qp))), comp + "_MSBD", qp, synth.trained_like_msbd_weights(comp, qp), source="test")
+    done = calibrate_pmpw.calibrate_dir(str(tmp_path), 0, log=lambda *a: None)
+    assert len(done) == 2
+    e = engine.Engine(0)
+    try:
+        for comp, qp in (("Luma", 22), ("Chroma", 37)):
+            man, tens = W.load_pmpw(str(tmp_path / ("%s_BD_%d.pmpw" % (comp, qp))))
+            ref = synth.trained_like_msbd_weights(comp, qp)
+            assert list(tens) == list(ref) and all(np.array_equal(tens[k], ref[k]) for k in ref)
+            e.load(comp, qp, msbd_weights=ref)                     # a calibrating load of the same tensors
+            assert man["act_exp"] == e.activation_report(comp, qp)["exps"]
+    finally:
+        e.close()
