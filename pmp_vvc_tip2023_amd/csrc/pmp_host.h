@@ -181,6 +181,16 @@ void free_net_weights(NetWeights &w);
 int set_activation_scales(pmp_ctx *c, NetWeights &w, const int exps[5]);
 constexpr int PMP_CAL_SLOTS = 128;
 
+// pmp_api.cpp internals that calibrate.cpp shares
+int ensure(pmp_ctx *c, DevBuf &b, size_t bytes);                    // grow-only device buffer (large workspaces come from the parked pool first)
+NetWeights *find_net(pmp_ctx *c, int net_id, int qp);               // loaded weights of (net, qp) or nullptr
+int run_graph_fn(pmp_ctx *c, const std::function<int()> &fwd);      // a forward graph twice: measuring pass, then the real one in c->ws
+int settle(pmp_ctx *c);                                             // everything asked of the context so far is done and final
+
+// calibrate.cpp
+int calibrate_mtt(pmp_ctx *c, bool luma, NetWeights &wq, NetWeights &wb);
+int calibrate_if_ready(pmp_ctx *c, int net_id, int qp);             // a (QT, MTT) pair that has just become complete, on the f16x3 datapath
+
 // nets.cpp: forward graphs on device pointers (n <= chunk); all launches go to c->stream.
 int forward_q(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, const uint8_t *bu, const uint8_t *bv,
               int n, float *qt);
