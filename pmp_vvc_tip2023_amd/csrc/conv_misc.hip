@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) void multipool_concat_kernel(const float *__re
     }
 }
 
-// ---- calibration of the f16x3 activation scales (pmp_api.cpp: calibrate_mtt): largest |value| of an fp32 tensor, folded into *slot as
+// ---- calibration of the f16x3 activation scales (calibrate.cpp: calibrate_mtt): largest |value| of an fp32 tensor, folded into *slot as
 // the magnitude's bit pattern (ordered like the floats; a NaN ranks above everything, split3.h).  Runs on a few dozen blocks once per
 // net, never on the inference path.
 __global__ __launch_bounds__(256) void amax_f32_kernel(const float *__restrict__ x, size_t n4, unsigned *slot)

@@ -42,7 +42,7 @@ struct Graph {
     int seg = 0;
     bool scaled() const { return h2() && c->act_scales && w.stem_b_h; }
     int E(int sg) const { return scaled() ? w.act_exp[sg] : 0; }
-    // calibration pass (fp32 datapath, pmp_api.cpp: calibrate_mtt): the largest |value| of a tensor just produced, per launch
+    // calibration pass (fp32 datapath, calibrate.cpp: calibrate_mtt): the largest |value| of a tensor just produced, per launch
     void note(const Act &a, const std::string &name, int sg)
     {
         if (!c->cal_on || !live() || a.split || (int)c->cal_log.size() >= PMP_CAL_SLOTS) return;

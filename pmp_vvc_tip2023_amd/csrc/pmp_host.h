@@ -56,7 +56,7 @@ struct NetWeights {
     // and the changes of scale cost nothing at run time: 2^-e0 is folded into the stem's output scale and biases (stem_b_h), 2^-e1 / 2^-e3
     // into the attention inputs where they are built, the step at a gate product into the out_scale of the convolution whose epilogue
     // multiplies (nets.cpp), the way back into the head weights (head_w_h = head_w * 2^e).  The exponents come from a calibration pass on the library's own extreme-content blocks, run once when
-    // the net is first used on the f16x3 datapath (pmp_api.cpp: calibrate_mtt); all zero = the arithmetic of a net without scales, bit for bit.
+    // the net is first used on the f16x3 datapath (calibrate.cpp: calibrate_mtt); all zero = the arithmetic of a net without scales, bit for bit.
     int act_exp[5] = {0, 0, 0, 0, 0};
     bool calibrated = false;
     float *stem_b_h = nullptr;                         // f16x3: stem biases * 2^-act_exp[0]

@@ -155,7 +155,7 @@ hipError_t launch_att_input(hipStream_t s, const float *q, const float *bt, cons
                             float scale = 1.f);     // scale: the f16x3 activation scale of the attention segment (a power of two)
 
 // Largest |value| of an fp32 tensor (n a multiple of 4), atomicMax'ed into *slot as the bit pattern of the magnitude: the calibration
-// pass of the f16x3 activation scales (pmp_api.cpp: calibrate_mtt).
+// pass of the f16x3 activation scales (calibrate.cpp: calibrate_mtt).
 hipError_t launch_amax_f32(hipStream_t s, const float *x, size_t n, unsigned *slot);
 
 // ------------------------------------------------------------------------------------------------ post-processing
