@@ -211,8 +211,13 @@ def trained_like_extra(eng, dev, n, step, timed):
         eng.load("Luma", 22, msbd_weights=synth.trained_like_msbd_weights("Luma", 22, **gains))
         rep = eng.activation_report("Luma", 22)
         eng.clear_saturation()
-        dt = timed(lambda: step("Luma", 22), 5)
+        from pmp_vvc_tip2023_amd import sensors
+        with sensors.Sampler(sensors.for_torch_device(dev.index or 0)) as smp:
+            dt = timed(lambda: step("Luma", 22), 5)
         eng.synchronize()
+        sm = smp.summary()
+        out["sclk_mhz_mean" + tag] = sm["sclk_mhz"]["mean"] if sm["sclk_mhz"] else None      # the same kernels on sparser activations: does the clock move?
+        out["power_w_mean" + tag] = sm["power_w"]["mean"] if sm["power_w"] else None
         out["ms_per_step" + tag] = round(dt * 1e3, 3)
         out["ctu_per_s" + tag] = round(n / 4.0 / dt, 2)
         out["saturation_reruns" + tag] = eng.saturation_reruns()
