@@ -99,3 +99,22 @@ def test_msbd_net_trained_like_weights(comp, qp):
     assert 300 < amax[1] < 3000 and 300 < amax[2] < 3000      # the trunks run where the trained QT nets run (SURVEY: 3e3 on 8-bit content)
     with pytest.raises(ValueError):
         synth.trained_like_msbd_weights(comp, qp, gate_gain=3.0)
+
+
+def test_trained_like_scale_table_matches_its_generator():
+    """pmp_vvc_tip2023_amd/trained_like_scales.json is the output of tools/calibrate_trained_like.py on synth.trained_like_raw(): a change to
+    the bootstrap without a regenerated table (or the other way round) must not go unnoticed.  One net re-calibrated here (torch CPU
+    convolutions: equal to the committed scalars up to the arithmetic of this host's convolution library)."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import calibrate_trained_like as C
+    c, outs = C.calibrate("Chroma", 37)
+    table = json.load(open(os.path.join(root, "pmp_vvc_tip2023_amd", "trained_like_scales.json")))["Chroma"]["37"]
+    assert set(c.scale) == set(table) and len(table) == 72
+    for name, want in table.items():
+        got = c.scale[name]
+        assert np.allclose(got, want, rtol=2e-3, atol=1e-4), (name, got, want)
+    assert 1500 < c.stats["x3"][0] < 2500 and 0.5 < c.stats["trunk_Att1.gate"][1] < 2.0
