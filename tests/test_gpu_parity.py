@@ -990,6 +990,14 @@ def test_bench_json_contract(tmp_path):
     e2e = d["e2e_host_buffers"]                 # the H2D/D2H-inclusive figure beside the device-resident one
     assert e2e["unit"] == "CTU/s" and 0 < e2e["value"] <= d["value"] * 1.5 and e2e["h2d_bytes_per_step"] == 64 * 68 * 68
     assert set(d["extra"]["luma_ctu_per_s_by_qp"]) == {"22", "27", "32", "37"} and d["extra"]["chroma_qp22_ctu_per_s"] > 0
+    # round 5: the step on trained-like MTT weights (no fp32 re-run, with and without the stress gains), this GPU's clock / power during the
+    # timed region, and what the whole host - not one calibrated process - does on the CPU path
+    tl = d["extra"]["trained_like"]
+    assert tl["saturation_reruns"] == 0 and tl["saturation_reruns_stress_k64_g16"] == 0 and tl["ms_per_step"] > 0
+    assert len(tl["activation_exps"]) == 5 and tl["activation_exps_stress_k64_g16"][0] >= tl["activation_exps"][0] + 5
+    assert "samples" in d["sensors"] and "sclk_mhz" in d["sensors"] and "power_w" in d["sensors"]
+    ac = cb["all_cores"]
+    assert "error" in ac or (ac["processes"] >= 1 and ac["blocks_per_s"] > 0 and "cpu_limits" in ac and cb["host_cores"] >= cb["cores"])
 
 
 def test_bench_launches_its_own_ranks(tmp_path):
