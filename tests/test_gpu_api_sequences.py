@@ -108,3 +108,64 @@ def test_random_api_sequences_are_result_neutral(seed):
         assert checked >= 20
     finally:
         e.close()
+
+
+def test_random_api_sequences_chroma():
+    """The same walk, shorter, on the chroma nets (three input planes, 32x32 trunks: every launch of the MTT net past the stem is a fused or
+    32x32 kernel there)."""
+    from pmp_vvc_tip2023_amd import engine, synth
+    rng = np.random.default_rng(31337)
+    dev = torch.device("cuda:0")
+    y, u, v = synth.recipe_r_blocks(1100, 98)
+    d = [torch.from_numpy(a).to(dev) for a in (y, u, v)]
+    kinds = {"benign": lambda: synth.synth_msbd_weights("Chroma", 27), "trained": lambda: synth.trained_like_msbd_weights("Chroma", 27),
+             "trained_k": lambda: synth.trained_like_msbd_weights("Chroma", 27, trunk_gain=4096.0, gate_gain=16.0, att_gain=8.0)}
+    refs = {}
+
+    def reference(kind, prec):
+        if (kind, prec) not in refs:
+            e = engine.Engine(0, allow_synthetic_mtt=True)
+            try:
+                e.set_precision(prec)
+                e.load("Chroma", 27, msbd_weights=kinds[kind]())
+                rec = torch.empty((y.shape[0], 1344), dtype=torch.uint8, device=dev)
+                e.infer_postprocess_records_device("Chroma", 27, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), y.shape[0], rec.data_ptr())
+                e.synchronize()
+                refs[(kind, prec)] = rec.cpu().numpy()
+            finally:
+                e.close()
+        return refs[(kind, prec)]
+
+    e = engine.Engine(0, allow_synthetic_mtt=True)
+    try:
+        kind, prec = "benign", "f16x3"
+        e.load("Chroma", 27, msbd_weights=kinds[kind]())
+        pending = []
+        for step in range(45):
+            op = rng.choice(["device", "device", "weights", "chunk", "fusion", "overlap", "precision", "sync"])
+            if op == "device":
+                n = int(rng.choice([2, 33, 257, 1030]))
+                lo = int(rng.integers(0, y.shape[0] - n + 1))
+                rec = torch.zeros((n, 1344), dtype=torch.uint8, device=dev)
+                e.infer_postprocess_records_device("Chroma", 27, d[0][lo:].data_ptr(), d[1][lo:].data_ptr(), d[2][lo:].data_ptr(), n, rec.data_ptr())
+                pending.append((rec, reference(kind, prec)[lo:lo + n], step, kind, prec))
+            elif op == "weights":
+                kind = str(rng.choice(list(kinds)))
+                e.load("Chroma", 27, msbd_weights=kinds[kind]())
+            elif op == "chunk":
+                e.set_chunk(int(rng.choice([7, 128, 4096])))
+            elif op == "fusion":
+                e.set_fusion(int(rng.integers(0, 4)))
+            elif op == "overlap":
+                e.set_overlap(bool(rng.integers(0, 2)))
+            elif op == "precision":
+                prec = str(rng.choice(["f16x3", "f16x3", "fp32"]))
+                e.set_precision(prec)
+            if op == "sync" or len(pending) >= 3 or step == 44:
+                e.synchronize()
+                for rec, want, st, k0, p0 in pending:
+                    assert np.array_equal(rec.cpu().numpy(), want), "chroma device call of step %d differs (%s, %s)" % (st, k0, p0)
+                pending = []
+        assert e.saturation_reruns() == 0
+    finally:
+        e.close()
