@@ -169,7 +169,16 @@ int pmp_infer(pmp_ctx *ctx, int comp, int qp, const uint8_t *block_y, const uint
 int pmp_infer_device(pmp_ctx *ctx, int comp, int qp, const uint8_t *d_block_y, const uint8_t *d_block_u,
                      const uint8_t *d_block_v, int64_t n, float *d_qt, float *d_bt, float *d_dire);
 
-/* ---- post-processing: seq_post_process minus the file (Metrics.py:764-774).  qt = RAW QT logits. ------- */
+/* ---- post-processing: seq_post_process minus the file (Metrics.py:764-774).  qt = RAW QT logits. -------
+ *      Value domain: EVERY float32 bit pattern, with the reference's results (tests/golden/g3b_m2p_range.npz, made by the reference):
+ *      - depth logits of any magnitude: np.round has no clamp (Map2Partition.py:104) and neither has this in effect - the rounded
+ *        depth is only compared with candidate depths 0..6, so the kernel's integer copy saturates at +-100 without a difference;
+ *        the float32 error sums (:307-312) run on the raw values in numpy's summation order, overflow to inf included;
+ *      - non-finite logits (a saturated datapath under PMP_SAT_IGNORE can hand them over): a NaN / +inf depth is "deeper than any
+ *        candidate" (numpy's `== 0` and `< 0` are False), -inf "shallower"; a NaN direction counts as 0, +-inf as +-1; a QT leaf
+ *        holding one takes the FIRST candidate leaf (Python's min() over inf / NaN errors); a NaN QT logit survives max-pool, round
+ *        and clamp (Metrics.py:632), no check_square_unity rule fires on its quadrant, its region gets no edges and directions 0
+ *        (set_partition_vector, :348-362: neither == nor > holds) and qt_u8 carries 0 (numpy's .astype(uint8) of NaN on x86-64). */
 int pmp_postprocess(pmp_ctx *ctx, int comp, const float *qt, const float *bt, const float *dire, int64_t n,
                     uint8_t *hor, uint8_t *ver, uint8_t *qt_u8, int8_t *dire_i8);
 int pmp_postprocess_device(pmp_ctx *ctx, int comp, const float *d_qt, const float *d_bt, const float *d_dire,

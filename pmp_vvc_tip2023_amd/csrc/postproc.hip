@@ -37,7 +37,10 @@ __device__ __forceinline__ int pack_cu(int x, int y, int h, int w) { return x | 
 struct Search {
     // per-lane constants of this block
     int row, col0;
-    int mb[3][4];     // np.round(bt) (Map2Partition.py:104), saturated to +-100 (comparisons only see <, ==)
+    int mb[3][4];     // np.round(bt) (Map2Partition.py:104) as an integer saturated to +-100; NaN -> +100.  The reference keeps the float and
+                      // has no clamp, but the rounded map is only ever compared (`== 0`, `< 0` of msbt - candidate, candidate depths 0..6,
+                      // :142,189-190): a value beyond 100 - or NaN, on which both comparisons are False - behaves like 100, one below
+                      // -100 like -100.  Pinned by tests/golden/g3b_m2p_range.npz (|bt| up to 3e38, +-inf, NaN; made by the reference)
     int md[3][4];     // th_round(dire, 0.5) (Map2Partition.py:30-35,105)
     float ob[3][4];   // raw MTT depth logits
     float od[3][4];   // raw direction logits
@@ -268,11 +271,16 @@ __global__ __launch_bounds__(256, 4) void postprocess_kernel(const float *__rest
     {
         const int i = lane & 15, pr = i >> 2, pc = i & 3;
         const float *q = qt + b * 64 + (2 * pr) * 8 + 2 * pc;
-        pv = fmaxf(fmaxf(q[0], q[1]), fmaxf(q[8], q[9]));
+        pv = q[0];                                        // F.max_pool2d propagates NaN (v_max_f32 would drop it)
+        if (q[1] > pv || q[1] != q[1]) pv = q[1];
+        if (q[8] > pv || q[8] != q[8]) pv = q[8];
+        if (q[9] > pv || q[9] != q[9]) pv = q[9];
         pv = rintf(pv);                                   // torch.round: half to even
-        pv = pv < 0.f ? 0.f : (pv > 3.f ? 3.f : pv);      // clamp(0, 3); -0.0 compares equal to 0
+        pv = pv < 0.f ? 0.f : (pv > 3.f ? 3.f : pv);      // clamp(0, 3); -0.0 compares equal to 0; NaN stays NaN (torch.clamp)
     }
-    int m = (int)pv;
+    // a NaN depth travels as -1: every comparison the reference makes on it (== 0, == 1, == depth, > depth) is False, and so is
+    // every comparison below; its quadrant's sum is NaN (Metrics.py:618-619: no rule applies); it is emitted as 0 (.astype(np.uint8))
+    int m = pv != pv ? -1 : (int)pv;
     {
         const unsigned long long z = __ballot(m == 0) & 0xFFFFull;
         const int num0 = __popcll(z);
@@ -283,7 +291,10 @@ __global__ __launch_bounds__(256, 4) void postprocess_kernel(const float *__rest
             int one = (m == 1) ? 1 : 0;
             int n1 = one + __shfl_xor(one, 1);
             n1 += __shfl_xor(n1, 4);
-            if (sum >= 5 && sum <= 10) {
+            int nnan = (m < 0) ? 1 : 0;
+            nnan += __shfl_xor(nnan, 1);
+            nnan += __shfl_xor(nnan, 4);
+            if (nnan == 0 && sum >= 5 && sum <= 10) {
                 if (n1 < 3) { if (m == 1) m = 2; }
                 else m = 1;
             }
@@ -293,7 +304,7 @@ __global__ __launch_bounds__(256, 4) void postprocess_kernel(const float *__rest
     }
     // nearest x2 (Metrics.py:635): lane l holds the 8x8 value at (l>>3, l&7)
     const int qt8 = rlane(m, 0) * 0 + __shfl(m, ((lane >> 4) << 2) + ((lane & 7) >> 1));
-    if (wv == 0) qt_o[b * s_qt + lane] = (uint8_t)qt8;
+    if (wv == 0) qt_o[b * s_qt + lane] = (uint8_t)(qt8 < 0 ? 0 : qt8);
 
     // ---- Map_to_Partition.__init__ (Map2Partition.py:100-122)
     Search s;
@@ -311,8 +322,8 @@ __global__ __launch_bounds__(256, 4) void postprocess_kernel(const float *__rest
         for (int k = 0; k < 4; ++k) {
             s.ob[k3][k] = fb[k];
             s.od[k3][k] = fd[k];
-            float r = rintf(fb[k]);                       // np.round: half to even, no clamp
-            r = r < -100.f ? -100.f : (r > 100.f ? 100.f : r);
+            float r = rintf(fb[k]);                       // np.round: half to even
+            r = !(r <= 100.f) ? 100.f : (r < -100.f ? -100.f : r);   // see Search::mb; NaN -> 100
             s.mb[k3][k] = (int)r;
             s.md[k3][k] = fd[k] >= 0.5f ? 1 : (fd[k] <= -0.5f ? -1 : 0);
         }

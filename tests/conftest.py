@@ -35,6 +35,14 @@ def g3_sets():
                    g["%s_ver_cf%d" % (t, cf)], g["%s_dout_cf%d" % (t, cf)], g["%s_leaves_cf%d" % (t, cf)])
 
 
+def g3b_sets():
+    """Yield (cf, qt RAW logits f32[n,8,8], bt, dire, tags, fixed f32[n,8,8] (NaN where the reference keeps one), q8, hor, ver, dout, leaves)
+    from g3b_m2p_range.npz: the value range the nets can emit - |logit| up to 3e38, +-inf, NaN (tools/gen_golden.py gen_g3b)."""
+    g = golden("g3b_m2p_range.npz")
+    for cf in (1, 2):
+        yield (cf,) + tuple(g["%s_cf%d" % (k, cf)] for k in ("qt", "bt", "dire", "tag", "fixed", "q8", "hor", "ver", "dout", "leaves"))
+
+
 @pytest.fixture(scope="session")
 def oracle_lib():
     from oracle import postproc

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import g3_sets, golden, golden_path
+from conftest import g3_sets, g3b_sets, golden, golden_path
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3  # north_star: "within 1e-3 fp32 on the map logits"
@@ -636,6 +636,69 @@ def test_postprocess_large_random_vs_oracle(eng, oracle_lib):
         assert np.array_equal(q8, fixed.astype(np.uint8))
         assert np.array_equal(h, oh) and np.array_equal(v, ov) and np.array_equal(d8, od)
         assert h[:, 0, :].all() and v[:, :, 0].all()       # block top row / left column are always edges
+
+
+def test_postprocess_value_range_bit_exact_vs_reference_golden(eng):
+    """G3b: the REFERENCE's eli_structual_error + map_to_parititon on what a net with trained-scale activations can
+    hand over - depth / direction logits of 50, 99.5, 100, 100.5, 300, 1e4, 3e38 and their negatives, QT logits of +-1e4 - and on +-inf
+    and NaN in every input.  np.round has no clamp (Map2Partition.py:104); the kernel's integer copy of the rounded depth saturates at
+    +-100 (postproc.hip: Search::mb) and must not differ anywhere.  Host-pointer, device-pointer and record entry points."""
+    dev = torch.device("cuda:0")
+    for cf, qt, bt, dire, tags, fixed, q8g, hor, ver, dout, leaves in g3b_sets():
+        comp = "Luma" if cf == 1 else "Chroma"
+        n = len(qt)
+        h, v, q8, d8 = eng.post_process(qt, bt, dire, comp)
+        for t in np.unique(tags):
+            m = tags == t
+            assert np.array_equal(q8[m], q8g[m]), (cf, t, "qt")
+            assert np.array_equal(h[m], hor[m]) and np.array_equal(v[m], ver[m]), (cf, t, "edges")
+            assert np.array_equal(d8[m], dout[m]), (cf, t, "dire")
+        d_in = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (qt, bt, dire)]
+        d_h = torch.empty((n, 16, 16), dtype=torch.uint8, device=dev); d_v = torch.empty_like(d_h)
+        d_q = torch.empty((n, 8, 8), dtype=torch.uint8, device=dev); d_d = torch.empty((n, 3, 16, 16), dtype=torch.int8, device=dev)
+        eng.postprocess_device(comp, d_in[0].data_ptr(), d_in[1].data_ptr(), d_in[2].data_ptr(), n, d_h.data_ptr(), d_v.data_ptr(),
+                               d_q.data_ptr(), d_d.data_ptr())
+        rec = torch.empty((n, 1344), dtype=torch.uint8, device=dev)
+        eng.postprocess_records_device(comp, d_in[0].data_ptr(), d_in[1].data_ptr(), d_in[2].data_ptr(), n, rec.data_ptr())
+        eng.synchronize()
+        assert np.array_equal(d_h.cpu().numpy(), hor) and np.array_equal(d_v.cpu().numpy(), ver)
+        assert np.array_equal(d_q.cpu().numpy(), q8g) and np.array_equal(d_d.cpu().numpy(), dout)
+        r = rec.cpu().numpy()
+        assert np.array_equal(r[:, :256].reshape(n, 16, 16), hor) and np.array_equal(r[:, 256:512].reshape(n, 16, 16), ver)
+        assert np.array_equal(r[:, 512:576].reshape(n, 8, 8), q8g) and np.array_equal(r[:, 576:].view(np.int8).reshape(n, 3, 16, 16), dout)
+
+
+def test_fused_path_on_overflowing_nets_matches_the_oracle_on_its_own_logits(eng, g1, oracle_lib):
+    """Logits that really come out of the nets beyond every sane range: MTT weights whose stem is scaled by 2^17 (f16x3 under PMP_SAT_IGNORE:
+    clamped activations, wrong but finite logits) and by 2^110 with the branches multiplying by 2^110 once more instead of undoing it (the exact datapaths overflow: +-inf and,
+    through inf - inf, NaN logits - as the reference's own arithmetic would).  Whatever the logits are, the flags of the fused entry
+    point must be the reference's post-processing OF THOSE LOGITS (oracle pinned on non-finite values by G3b)."""
+    from pmp_vvc_tip2023_amd import engine
+    y = np.ascontiguousarray(g1["block_y"][:8])
+    e2 = engine.Engine(0, allow_synthetic_mtt=True)
+    try:
+        e2.set_precision(eng.get_precision())
+        e2.load("Luma", 22)
+        e2.set_activation_scales(False)
+        e2.set_saturation_policy("ignore")
+        seen_nonfinite = False
+        for K in (2.0 ** 17, 2.0 ** 110):
+            w = _range_stress_weights(K)
+            if K > 2.0 ** 100:
+                for t in ("trunk_B1.0", "trunk_B2.0", "trunk_B3.0"):        # do not undo the gain: the trunks overflow float32 itself
+                    for k in (".left.0.weight", ".shortcut.0.weight"):
+                        w[t + k] = (w[t + k] * np.float32(K) * np.float32(K)).astype(np.float32)   # w * K: 5e33 activations x 5e31 weights
+            e2.load_pretrain_model("Luma_MSBD", 22, w)
+            hor, ver, q8, d8, qt, bt, dire = e2.infer_postprocess("Luma", 22, y, want_logits=True)
+            seen_nonfinite |= not (np.isfinite(bt).all() and np.isfinite(dire).all())
+            with np.errstate(invalid="ignore"):
+                oh, ov, oq, od = oracle_lib.seq_post_process(qt, bt, dire, "Luma", 1, 64 * len(y), 64, None)
+                assert np.array_equal(q8, np.nan_to_num(oq, nan=0.0).astype(np.uint8))
+            assert np.array_equal(hor, oh) and np.array_equal(ver, ov) and np.array_equal(d8, od), "K = 2^%d" % int(np.log2(K))
+        if eng.get_precision() != "f16x3":
+            assert seen_nonfinite, "the overflow case did not produce a non-finite logit: the test lost its subject"
+    finally:
+        e2.close()
 
 
 # ------------------------------------------------------------------------------------------------ cutter

@@ -26,8 +26,9 @@ def _clean_env(**extra):
 
 
 # ------------------------------------------------------------------------------------------------ the tail at full size
-@pytest.mark.parametrize("comp,qp,n", [("Luma", 22, 4096), ("Luma", 27, 2048), ("Luma", 32, 1024), ("Luma", 37, 1024), ("Chroma", 22, 4096)])
-def test_full_size_logit_tail_default_datapath_and_guard_fallback(comp, qp, n):
+@pytest.mark.parametrize("comp,qp,n,mtt", [("Luma", 22, 4096, "trained_like"), ("Luma", 27, 2048, "uniform"), ("Luma", 32, 1024, "uniform"),
+                                           ("Luma", 37, 1024, "trained_like"), ("Chroma", 22, 4096, "uniform")])
+def test_full_size_logit_tail_default_datapath_and_guard_fallback(comp, qp, n, mtt):
     """4096 fresh recipe-R luma blocks (the campaign's seeds, tests/campaign_gpu.py): max |logit - oracle| < 1e-3 on the default f16x3
     datapath and on the exact fp32 MFMA datapath the range guard falls back to.  The 512-block tests sit at 1.9e-4; the tail at this
     size is 6.2e-4 / 5.6e-4 (profiles/r03_parity_campaign.txt) - Luma_Q's conditioning at low QP, the torch oracle itself is 3.3e-4
@@ -39,30 +40,43 @@ def test_full_size_logit_tail_default_datapath_and_guard_fallback(comp, qp, n):
     (round 5: the fp32 fallback is 7.6e-4 from the oracle on Luma QP27 at 15 840 blocks, profiles/r04_campaign_config4_all.txt; its old
     6.5e-4 bound on the maximum was a sample of the same chaotic tail).  Round 5 also puts Chroma QP22 at full size and Luma QP32 / QP37 at
     1024 blocks under the driver's eyes, and halves Luma QP27 to 2048 to pay for them (the oracle costs ~75 s per 4096 luma blocks on 16
-    host threads and the suite has a time budget; every net at 4096 and 15 840 blocks: tests/campaign_gpu.py)."""
+    host threads and the suite has a time budget; every net at 4096 and 15 840 blocks: tests/campaign_gpu.py).
+    Round 6: the Luma QP22 case at 4096 blocks and Luma QP37 run on the TRAINED-LIKE MTT weights (synth.py; the uniform
+    synthetic ones keep Luma QP27 / QP32, Chroma QP22, bench.py's parity sample and test_config2_full_batch_properties) - the absolute 1e-3
+    on every one of 4096 blocks of a net with trunks at 1e3 and gate products at 1e4, no re-run - and the split flags of those device
+    logits are the oracle's, bit for bit.  The fp32 fallback keeps a bound on its maximum again (8.5e-4: 7.6e-4 is the largest value any
+    campaign saw on it) beside the quantile trip wire."""
     from oracle import nets_torch as O
     from pmp_vvc_tip2023_amd import engine, synth, weights as W
     luma = comp == "Luma"
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     y, u, v = synth.recipe_r_blocks(n, 5000 + qp + (0 if luma else 500))
     wq, _ = W.load_net_weights(comp + "_Q", qp)
-    wbd, _ = W.load_net_weights(comp + "_MSBD", qp, allow_synthetic=True)
+    if mtt == "trained_like":
+        wbd = synth.trained_like_msbd_weights(comp, qp)
+    else:
+        wbd, _ = W.load_net_weights(comp + "_MSBD", qp, allow_synthetic=True)
     oq, obt, od = O.infer_qbd(wq, wbd, O.luma_input(y) if luma else O.chroma_input(y, u, v), luma, batch=64)
     e = engine.Engine(0, allow_synthetic_mtt=True)
     try:
         out = {}
+        e.load(comp, qp, msbd_weights=wbd if mtt == "trained_like" else None)
         for prec in ("f16x3", "fp32"):
             e.set_precision(prec)
-            qt, bt, dire = e.inference_pre_QBD(comp, qp, y, u, v)
-            assert not e.saturated()
+            hor, ver, q8, d8, qt, bt, dire = e.infer_postprocess(comp, qp, y, u, v, want_logits=True)
+            assert not e.saturated() and e.saturation_reruns() == 0
+            if prec == "f16x3":
+                from oracle import postproc as P
+                oh, ov, of, odd = P.seq_post_process(qt, bt, dire, comp, 1, 64 * n, 64, None)
+                assert np.array_equal(hor, oh) and np.array_equal(ver, ov) and np.array_equal(d8, odd) and np.array_equal(q8, of.astype(np.uint8))
             per_block = np.maximum(np.abs(qt - oq).reshape(n, -1).max(1),
                                    np.maximum(np.abs(bt - obt).reshape(n, -1).max(1), np.abs(dire - od).reshape(n, -1).max(1)))
             out[prec] = per_block
-            print("\n  %s QP%d %-5s %d blocks: max |logit - oracle| %.2e (margin %.2fx inside 1e-3), per block median %.1e p99 %.1e p99.9 %.1e"
-                  % (comp, qp, prec, n, per_block.max(), TOL / per_block.max(), np.median(per_block), np.quantile(per_block, 0.99),
+            print("\n  %s QP%d (%s MTT weights) %-5s %d blocks: max |logit - oracle| %.2e (margin %.2fx inside 1e-3), per block median %.1e p99 %.1e p99.9 %.1e"
+                  % (comp, qp, mtt, prec, n, per_block.max(), TOL / per_block.max(), np.median(per_block), np.quantile(per_block, 0.99),
                      np.quantile(per_block, 0.999)), flush=True)
         for prec, pb in out.items():
-            assert pb.max() < TOL, "%s QP%d on %s: logits off by %g" % (comp, qp, prec, pb.max())
+            assert pb.max() < (TOL if prec == "f16x3" else 8.5e-4), "%s QP%d on %s: logits off by %g" % (comp, qp, prec, pb.max())
             q99, q999 = np.quantile(pb, 0.99), np.quantile(pb, 0.999)
             assert q99 < 2.5e-4 and q999 < 5.5e-4, "%s QP%d on %s: the tail moved: p99 %.2e, p99.9 %.2e (round 4, f16x3: 1.9e-4 / 4.4e-4 at Luma QP22)" % (comp, qp, prec, q99, q999)
     finally:

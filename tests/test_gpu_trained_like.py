@@ -77,27 +77,34 @@ def _oracle(comp, qp, n):
     return _ORACLE[key]
 
 
+# Blocks of _oracle()'s set that an OPT-IN datapath puts outside the plain 1e-3 on the QT logits (Luma_Q's conditioning at low QP leaves
+# bf16x6 no margin): excluded BY INDEX from the QT assertion of that datapath - every other block, and every block on
+# the default datapath and on fp32, gets the plain tolerance.
+_QT_KNOWN = {("bf16x6", "Luma", 22): (), ("fp32", "Luma", 22): ()}
+
+
 @pytest.mark.parametrize("comp,qp", [("Luma", 22), ("Luma", 37), ("Chroma", 27), ("Chroma", 37)])
-def test_trained_like_fresh_blocks_vs_oracle(eng, comp, qp):
+def test_trained_like_fresh_blocks_vs_oracle(eng, oracle_lib, comp, qp):
     """320 fresh blocks (flat, saturated, white-noise and checkerboard blocks included) against the torch oracle holding the same
-    tensors; the record of what the guard did rides along."""
+    tensors: north_star's ABSOLUTE 1e-3 on every block whose logits are inside Map2Partition's operating range (|logit| <= 8), and at
+    most 2 % of the natural blocks may lie outside it; the record of what the guard did rides along.  Then the DEVICE logits of all 320
+    blocks - the checkerboard's +-300 and the noise block's +-75 among them - through pmp_postprocess against the oracle's
+    post-processing of the same numbers (the kernel's +-100 saturation of the rounded depth sees real net output)."""
     y, u, v, oq, obt, odire = _oracle(comp, qp, 320)
     _load_tl(eng, comp, qp)
     eng.clear_saturation()
-    qt, bt, dire = eng.inference_pre_QBD(comp, qp, y, u, v)
-    # per block: north_star's absolute 1e-3 wherever the logits are in Map2Partition's operating range (|logit| <= 8: every natural block);
-    # the synthetic extremes (2-px checkerboard: logits of +-300, white noise: +-75) get the same tolerance RELATIVE to their logits - the
-    # torch oracle itself is 6.6e-4 from an fp64 evaluation on the checkerboard block
+    hor, ver, q8, d8, qt, bt, dire = eng.infer_postprocess(comp, qp, y, u, v, want_logits=True)
+
     def per_block(pairs):
         e = np.max([np.abs(a - b).reshape(len(a), -1).max(axis=1) for a, b in pairs], axis=0)
         m = np.max([np.abs(b).reshape(len(b), -1).max(axis=1) for _, b in pairs], axis=0)
-        return e, m, TOL * np.maximum(1.0, m / 8.0)
-    e_q, m_q, tol_q = per_block([(qt, oq)])
-    # (the QT nets are not this test's subject - their parity has its own tests - but they run first.  On these blocks the bf16x6 datapath
-    # puts ONE natural Luma QP22 block at 1.02e-3 from the oracle, the default datapath and fp32 stay inside 1e-3: Luma_Q's conditioning at
-    # low QP, DESIGN.md section 6; the opt-in datapaths get 1.25e-3 here so that the MTT assertions below are reached, the default one does not)
-    slack = 1.0 if eng.get_precision() == "f16x3" else 1.25
-    assert (e_q < slack * tol_q).all(), "QT logits: block %d off by %g" % (int(np.argmax(e_q / tol_q)), e_q.max())
+        return e, m
+    # the QT nets (real weights; not this test's subject, but they run first): plain 1e-3 on every block
+    e_q, _ = per_block([(qt, oq)])
+    known = _QT_KNOWN.get((eng.get_precision(), comp, qp), ())
+    over = [int(i) for i in np.flatnonzero(e_q >= TOL) if int(i) not in known]
+    assert not over, "QT logits: blocks %s off by %s" % (over, e_q[over])
+    assert all(e_q[i] < 1.25 * TOL for i in known)
     # (a) the MTT net ALONE on identical inputs: the oracle fed with the QT logits the HIP path produced
     from oracle import nets_torch as O
     from pmp_vvc_tip2023_amd import synth
@@ -106,17 +113,31 @@ def test_trained_like_fresh_blocks_vs_oracle(eng, comp, qp):
     with torch.no_grad():
         o = O.msbd_forward(synth.trained_like_msbd_weights(comp, qp), x, torch.from_numpy(qt), luma)
     abt = np.stack([t[:, 0].numpy() for t in o], 1); adire = np.stack([t[:, 1].numpy() for t in o], 1)
-    e_a, m_a, tol_a = per_block([(bt, abt), (dire, adire)])
-    assert (e_a < tol_a).all(), "%s QP%d MTT net on identical inputs: block %d off by %g" % (comp, qp, int(np.argmax(e_a / tol_a)), e_a[np.argmax(e_a / tol_a)])
+    e_a, m_a = per_block([(bt, abt), (dire, adire)])
     # (b) end to end, QT net included: the oracle's own q feeds the oracle's MTT net (the trained-like nets pass an error of q on
     # 0.5..1.7x, synth.py: _TL_Q_STEM)
-    e_blk, mag, tol = per_block([(bt, obt), (dire, odire)])
-    worst = int(np.argmax(e_blk / tol))
-    print("trained-like %s QP%d %s: MTT alone max %.2e | end to end worst block %d: %.2e at |logit| %.1f (natural blocks: max %.2e), reruns %d"
-          % (comp, qp, eng.get_precision(), e_a[4:].max(), worst, e_blk[worst], mag[worst], e_blk[4:].max(), eng.saturation_reruns()))
-    assert (e_blk < tol).all(), "%s QP%d block %d off by %g (|logit| %g)" % (comp, qp, worst, e_blk[worst], mag[worst])
-    assert np.quantile(mag[4:], 0.95) <= 16                       # the recipe-R blocks ARE in (or next to) the operating range
+    e_b, m_b = per_block([(bt, obt), (dire, odire)])
+    inside = np.maximum(m_a, m_b) <= 8.0
+    natural = np.arange(len(y)) >= 4
+    n_out = int((natural & ~inside).sum())
+    worst = int(np.argmax(np.where(inside, e_b, 0)))
+    print("trained-like %s QP%d %s: |logit| <= 8 on %d of %d natural blocks; inside: MTT alone max %.2e, end to end max %.2e (block %d); "
+          "outside (relative to |logit|/8): max %.2e; reruns %d" % (comp, qp, eng.get_precision(), int((natural & inside).sum()), int(natural.sum()),
+          e_a[inside].max(), e_b[worst], worst, (e_b / np.maximum(1.0, m_b / 8.0))[~inside].max() if (~inside).any() else 0.0, eng.saturation_reruns()))
+    assert (e_a[inside] < TOL).all(), "%s QP%d MTT net on identical inputs: block %d off by %g" % (comp, qp, int(np.argmax(np.where(inside, e_a, 0))), e_a[inside].max())
+    assert (e_b[inside] < TOL).all(), "%s QP%d end to end: block %d off by %g (|logit| %g)" % (comp, qp, worst, e_b[worst], m_b[worst])
+    assert n_out <= 0.02 * natural.sum(), "%d of %d natural blocks leave the operating range: the absolute tolerance covers too little" % (n_out, int(natural.sum()))
+    # beyond the operating range - the synthetic extremes (2-px checkerboard: +-300, white noise: +-75; the torch oracle itself is 6.6e-4 from
+    # an fp64 evaluation on the checkerboard block) and the few natural blocks counted above - the same tolerance RELATIVE to |logit| / 8
+    assert (e_a[~inside] < TOL * np.maximum(1.0, m_a[~inside] / 8.0)).all() and (e_b[~inside] < TOL * np.maximum(1.0, m_b[~inside] / 8.0)).all()
+    assert max(m_b[:4].max(), m_a[:4].max()) > 50 or not luma    # the extremes ARE extreme (luma): the post-processing below sees them
     assert eng.saturation_reruns() == 0
+    # the split flags of the fused call = the reference's post-processing of ITS device logits, the +-300 blocks included
+    with np.errstate(invalid="ignore"):
+        oh, ov, of, od = oracle_lib.seq_post_process(qt, bt, dire, comp, 1, 64 * len(y), 64, None)
+    assert np.array_equal(hor, oh) and np.array_equal(ver, ov) and np.array_equal(d8, od) and np.array_equal(q8, of.astype(np.uint8))
+    h2, v2, q82, d82 = eng.post_process(qt, bt, dire, comp)       # and through the host-pointer seam (pmp_postprocess)
+    assert np.array_equal(hor, h2) and np.array_equal(ver, v2) and np.array_equal(q8, q82) and np.array_equal(d8, d82)
 
 
 @pytest.mark.parametrize("comp,qp", [("Luma", 22), ("Chroma", 27)])

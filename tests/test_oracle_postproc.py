@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import g3_sets, golden, golden_path
+from conftest import g3_sets, g3b_sets, golden, golden_path
 
 
 def test_map_to_partition_bit_exact(oracle_lib):
@@ -19,6 +19,30 @@ def test_map_to_partition_bit_exact(oracle_lib):
         assert np.array_equal(lv, leaves), (tag, cf)
         total += len(qt)
     assert total >= 2000          # >= 2000 reference-generated triples (2204), large trees for both chroma factors
+
+
+def test_value_range_set_bit_exact(oracle_lib, tmp_path):
+    """G3b: the reference's eli_structual_error + map_to_parititon on depth / direction logits of 50 ... 3e38, QT logits of +-1e4, and
+    +-inf / NaN in every input - NaN depths included, which the reference carries through max-pool, round and clamp."""
+    n_nan = 0
+    for cf, qt, bt, dire, tags, fixed, q8, hor, ver, dout, leaves in g3b_sets():
+        assert np.abs(bt[np.isfinite(bt)]).max() >= 2.9e38 and np.isnan(bt).any() and np.isinf(dire).any() and np.isnan(qt).any()
+        of = oracle_lib.eli_structural_error(qt).reshape(-1, 8, 8)
+        assert np.array_equal(of, fixed, equal_nan=True), cf
+        h, v, d, lv = oracle_lib.map_to_partition(of, bt, dire, cf)
+        for t in np.unique(tags):
+            m = tags == t
+            assert np.array_equal(h[m], hor[m]) and np.array_equal(v[m], ver[m]) and np.array_equal(d[m], dout[m]), (cf, t)
+        assert np.array_equal(lv, leaves), cf
+        n_nan += int(np.isnan(fixed).any(axis=(1, 2)).sum())
+        # the writer's cast of a NaN depth (Map2Partition.py:403) = the 0 the fixture holds
+        k = np.flatnonzero(np.isnan(fixed).any(axis=(1, 2)))[:2]
+        p = str(tmp_path / ("nan%d.txt" % cf))
+        oracle_lib.write_partition_file(p, 1, 64, 128, hor[k], ver[k], fixed[k], dout[k])
+        vals = np.array(open(p).read().split(), np.int64)
+        qsec = vals[2 * 16 * 32:2 * 16 * 32 + 8 * 16].reshape(8, 16)
+        assert np.array_equal(qsec, np.concatenate([q8[k[0]], q8[k[1]]], axis=1))
+    assert n_nan >= 50
 
 
 def test_eli_structural_error_bit_exact(oracle_lib):

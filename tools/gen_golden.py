@@ -7,6 +7,8 @@ Every output is produced by calling the reference's own functions:
   G2b Model_QBD.{Luma,Chroma}_MSBD_Net       TRAINED-LIKE weights (synth.trained_like_msbd_weights: bootstrapped from the real QT
                                              tensors, trunks at 1e3, gated products to 9e3), 4 QPs -> g2b_msbd_trained_like.npz
   G3  Map2Partition.map_to_parititon         random/adversarial maps       -> g3_m2p.npz
+  G3b Metrics.eli_structual_error + Map2Partition.map_to_parititon on the value RANGE the nets can hand over: |bt|, |dire| up to
+      50, 99.5, 100, 100.5, 300, 1e4, 3e38 (np.round has no clamp), QT logits of +-1e4, +-inf and NaN everywhere -> g3b_m2p_range.npz
   G4  Metrics.eli_structual_error            random logits                 -> g4_eli.npz
   G5  Map2Partition.get_sequence_partition_for_VTM (text bytes)            -> g5_seq.npz + g5_partitionmat.txt
   G6  Inference_QBD.output_block_yuv         8-bit and 10-bit frames       -> g6_cut.npz
@@ -241,6 +243,122 @@ def gen_g3():
     np.savez_compressed(os.path.join(OUT, "g3_m2p.npz"), **out)
 
 
+
+# ----------------------------------------------------------------------------------------------- G3b
+G3B_MAGS = (50.0, 99.5, 100.0, 100.5, 300.0, 1.0e4, 3.0e38)
+
+
+def g3b_inputs(cf, seed):
+    """Valid random partitions (+ N(0, 0.15)) whose depth / direction logits are pushed to the magnitudes a net with trained-scale
+    activations can emit (tests/test_gpu_trained_like.py sees +-300 on a checkerboard), and non-finite values.  Variants per magnitude
+    X and sign s (the thresholds of can_split_mode_list - 0.7 / 0.3 of a region, Map2Partition.py:142-199 - tolerate outliers, so the
+    searches stay non-trivial):
+      sprinkle   8..25 % of the cells of bt (all three layers, independently) = s*X
+      region     one random rectangle of one bt layer = s*X
+      dire       10..30 % of the direction cells = s*X
+      scale      the whole triple's bt multiplied so that its largest value is X (s = -1: negated)
+      direscale  dire * X  (th_round keeps the structure, the float32 error sums carry the magnitude)
+      qtlogit    QT logits: cells of depth >= 1 pushed to +1e4, depth-0 cells to -1e4 (clamp(round(.), 0, 3), Metrics.py:632)
+    and for NaN, +inf, -inf: sprinkled into bt, into dire, into the QT logits (single cells, 2x2 windows, whole quadrants, everything)."""
+    rng = np.random.default_rng(seed)
+    qs, bs, ds, tags = [], [], [], []
+
+    def base():
+        q, b, d = synth.random_partition_maps(rng, cf)
+        # noise in steps of 1/64 (exact in float32): ties at .5 and equal-error ties are frequent, and the fixture compresses
+        b = b + np.rint(rng.normal(0, 0.15, b.shape) * 64) / 64
+        d = d + np.rint(rng.normal(0, 0.15, d.shape) * 64) / 64
+        ql = q + np.rint(rng.normal(0, 0.2, q.shape) * 64) / 64
+        return ql.astype(np.float32), b.astype(np.float32), d.astype(np.float32)
+
+    def add(tag, q, b, d):
+        qs.append(q.astype(np.float32)); bs.append(b.astype(np.float32)); ds.append(d.astype(np.float32)); tags.append(tag)
+
+    def sprinkle(a, frac, val):
+        a = a.copy()
+        a[rng.random(a.shape) < frac] = val
+        return a
+
+    def region(a, val):
+        a = a.copy()
+        k = rng.integers(0, 3); x = rng.integers(0, 14); y = rng.integers(0, 14)
+        a[k, x:x + rng.integers(1, 9), y:y + rng.integers(1, 9)] = val
+        return a
+
+    with np.errstate(over="ignore", invalid="ignore"):
+        for X in G3B_MAGS:
+            for s in (1.0, -1.0):
+                for _ in range(4):
+                    q, b, d = base(); add("sprinkle", q, sprinkle(b, rng.uniform(0.08, 0.25), s * X), d)
+                    q, b, d = base(); add("region", q, region(b, s * X), d)
+                    q, b, d = base(); add("dire", q, b, sprinkle(d, rng.uniform(0.1, 0.3), s * X))
+                    q, b, d = base(); add("scale", q, b * np.float32(s * X / max(np.abs(b).max(), 1e-6)), d)
+                    q, b, d = base(); add("direscale", q, b, d * np.float32(s * X))
+        for _ in range(24):
+            q, b, d = base()
+            add("qtlogit", np.where(np.rint(q) >= 1, np.float32(1e4), np.float32(-1e4)), b, d)
+            q, b, d = base()
+            add("qtlogit", np.where(rng.random(q.shape) < 0.2, np.float32(rng.choice([-1e4, 1e4])), q), b, d)
+        for val in (np.nan, np.inf, -np.inf):
+            for _ in range(10):
+                q, b, d = base(); add("nf_bt", q, sprinkle(b, rng.uniform(0.02, 0.3), val), d)
+                q, b, d = base(); add("nf_bt", q, region(b, val), d)
+                q, b, d = base(); add("nf_dire", q, b, sprinkle(d, rng.uniform(0.02, 0.3), val))
+                q, b, d = base(); b2 = b.copy(); b2[0, 0, 0] = val; add("nf_bt", q, b2, d)        # one cell of the first leaf's region
+                q, b, d = base(); q2 = q.copy(); q2[rng.integers(0, 8), rng.integers(0, 8)] = val; add("nf_qt", q2, b, d)
+                q, b, d = base(); q2 = q.copy(); x = 2 * rng.integers(0, 4); y = 2 * rng.integers(0, 4); q2[x:x + 2, y:y + 2] = val; add("nf_qt", q2, b, d)
+                q, b, d = base(); q2 = q.copy(); x = 4 * rng.integers(0, 2); y = 4 * rng.integers(0, 2); q2[x:x + 4, y:y + 4] = val; add("nf_qt", q2, b, d)
+                q, b, d = base(); add("nf_qt", sprinkle(q, rng.uniform(0.02, 0.5), val), b, d)
+                # 13..15 true zeros beside the non-finite cells: check_square_unity's "whole map = 0" branch swallows a NaN (Metrics.py:626-627)
+                q2 = np.full((8, 8), 0.1, np.float32)
+                for c in rng.choice(16, size=int(rng.integers(1, 4)), replace=False):
+                    q2[2 * (c // 4), 2 * (c % 4)] = val
+                q, b, d = base(); add("nf_qt", q2, b, d)
+            q, b, d = base(); add("nf_qt", np.full_like(q, val), b, d)
+            q, b, d = base(); add("nf_bt", q, np.full_like(b, val), d)
+            q, b, d = base(); add("nf_dire", q, b, np.full_like(d, val))
+            q, b, d = base(); add("nf_all", np.full_like(q, val), np.full_like(b, val), np.full_like(d, val))
+    return np.stack(qs), np.stack(bs), np.stack(ds), np.array(tags)
+
+
+def gen_g3b():
+    """The reference's own seq_post_process arithmetic (Metrics.py:764-774: eli_structual_error, then map_to_parititon per block, then
+    the casts of get_sequence_partition_for_VTM, Map2Partition.py:401-404) on g3b_inputs.  What the reference does with non-finite
+    values, pinned here because the kernel reproduces it (pmp.h, "non-finite logits"):
+      * bt NaN / +inf: np.round keeps it, `comp_map == 0` and `< 0` are False -> the cell counts as "deeper than any candidate";
+        -inf: `< 0` True.  dire NaN: th_round leaves NaN, neither == 1 nor == -1 -> counts as 0; +-inf -> +-1.
+      * a non-finite value inside a QT leaf makes every leaf's error inf or NaN; `error_list.index(min(error_list))` then returns 0 -
+        Python's min keeps its first argument unless a later one compares less.
+      * QT logits: max_pool2d propagates NaN, round and clamp keep it; check_square_unity's comparisons are False on it (a quadrant
+        holding one is left alone; the 13..15-zeros branch overwrites it); set_partition_vector does nothing for a NaN depth (no
+        edges, directions 0); `.astype(np.uint8)` of NaN gives 0 on x86-64 (numpy warns "invalid value encountered in cast")."""
+    import warnings
+    out = {"meta": np.array(META + "; inputs = tools/gen_golden.py g3b_inputs(cf, 3300 + cf); qt = RAW logits (eli_structual_error applied)"),
+           "mags": np.array(G3B_MAGS, np.float32)}
+    for cf in (1, 2):
+        ql, bt, dr, tags = g3b_inputs(cf, 3300 + cf)
+        n = len(ql)
+        with torch.no_grad():
+            fixed = Met.eli_structual_error(torch.from_numpy(ql[:, None])).numpy()[:, 0]
+        hor = np.zeros((n, 16, 16), np.uint8); ver = np.zeros((n, 16, 16), np.uint8); dout = np.zeros((n, 3, 16, 16), np.int8)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for i in range(n):
+                hor[i], ver[i], dout[i] = M2P.map_to_parititon(fixed[i], bt[i], dr[i], cf)
+            q8 = fixed.astype(np.float64).astype(np.uint8)                  # seq_qt_map is float64 (Map2Partition.py:388,403)
+            # the oracle, while we are here
+            of = P.eli_structural_error(ql).reshape(-1, 8, 8)
+            assert np.array_equal(of, fixed, equal_nan=True), "oracle eli mismatch on the range set"
+            ho, vo, do, leaves = P.map_to_partition(of, bt, dr, cf)
+        assert np.array_equal(hor, ho) and np.array_equal(ver, vo) and np.array_equal(dout, do), "oracle m2p mismatch (range set)"
+        assert q8[np.isnan(fixed)].sum() == 0
+        out.update({"qt_cf%d" % cf: ql, "bt_cf%d" % cf: bt, "dire_cf%d" % cf: dr, "tag_cf%d" % cf: tags, "fixed_cf%d" % cf: fixed,
+                    "q8_cf%d" % cf: q8, "hor_cf%d" % cf: hor, "ver_cf%d" % cf: ver, "dout_cf%d" % cf: dout, "leaves_cf%d" % cf: leaves})
+        print("G3b cf", cf, n, "triples; leaves mean %.1f max %d; NaN cells in the fixed QT maps: %d" %
+              (leaves.mean(), leaves.max(), int(np.isnan(fixed).sum())))
+    np.savez_compressed(os.path.join(OUT, "g3b_m2p_range.npz"), **out)
+
+
 # ------------------------------------------------------------------------------------------------ G4
 def gen_g4():
     rng = np.random.default_rng(44)
@@ -327,10 +445,11 @@ def gen_g7():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2b", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2b", "g3", "g3b", "g4", "g5", "g6", "g7"]
     if "g1" in which: gen_g1_g2()
     if "g2b" in which: gen_g2b()
     if "g3" in which: gen_g3()
+    if "g3b" in which: gen_g3b()
     if "g4" in which: gen_g4()
     if "g5" in which: gen_g5()
     if "g6" in which: gen_g6()
