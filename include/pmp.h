@@ -18,7 +18,12 @@
  * Conventions
  *   - Every call returns 0 (PMP_OK) or a negative error class; pmp_last_error() gives the message.  Nothing
  *     aborts or throws across the ABI; HIP errors are mapped to PMP_E_HIP.
- *   - One context per GPU.  A context is not thread-safe; different contexts are independent.
+ *   - One context per GPU (several per GPU work too).  A context is not thread-safe: one host thread at a time per context.  Different
+ *     contexts are independent and may be driven from different host threads CONCURRENTLY - everything a call touches hangs off its
+ *     context (streams, workspaces, weights, calibration stream and workspace, range-guard queue, error string); the only
+ *     process-wide state is the pool of parked workspaces behind pmp_destroy / pmp_trim (mutex-protected) and the calling thread's
+ *     context-less error string (thread-local).  tests/test_gpu_threads.py: two contexts on two threads = the serial results, bit
+ *     for bit.  (pmp_debug_set_conv_variant has no state in this library; in the measurement library it is process-wide.)
  *   - There is NO CPU fallback: every compute entry point needs a context on a gfx950 device.
  *   - "block" = one 64x64 luma region with its 4-pixel top/left context: u8[68][68] luma, u8[34][34] per chroma
  *     plane (Inference_QBD.py:190-191).  One VTM CTU (128x128) = 4 blocks.
@@ -143,7 +148,9 @@ int pmp_get_precision(const pmp_ctx *ctx);
  * call that completes the pair (≈ 20 ms of host time; the pass runs on a private stream and a private 44 MB workspace, beside whatever the
  * context's stream is doing) - or, for a pair loaded under another datapath, at its first f16x3 inference call.  NOT AT ALL for an MTT
  * file whose .pmpw manifest carries "act_exp": [e0..e4] (tools/calibrate_pmpw.py writes them once per model directory): those exponents
- * are taken as they are.
+ * are taken as they are - bounded by the reader (0..30 for the trunk segments, 0..6 for the attention segments: PMP_E_INVALID beyond), and
+ * only if the manifest's "act_fp" fingerprints match the tensors of the file and of the QT partner that is (or later gets) loaded; a stale
+ * manifest falls back to the calibration pass, and (re)loading a QT net drops exponents that were derived with another one.
  * pmp_debug_activation_report (below) returns the exponents and the recorded maxima. */
 #define PMP_SAT_RERUN 0
 #define PMP_SAT_ERROR 1
@@ -162,6 +169,13 @@ int pmp_load_weights(pmp_ctx *ctx, int net_id, int qp, const float *blob, const 
  * The manifest's net and QP must match the arguments. */
 int pmp_load_weights_file(pmp_ctx *ctx, int net_id, int qp, const char *path);
 int pmp_has_weights(const pmp_ctx *ctx, int net_id, int qp);
+/* Fingerprint of a loaded net's tensors / of a tensor set (names, shapes, float bit patterns; independent of the order and layout they
+ * are handed over in; weights.fingerprint() computes the same number with numpy).  What ties a manifest's "act_exp" to the tensors it
+ * was calibrated on: tools/calibrate_pmpw.py stores "act_fp": [this net's, its QT partner's] beside the exponents, and
+ * pmp_load_weights_file ignores exponents whose fingerprints do not match what is loaded (stale file: the QT net or the tensors changed
+ * since) in favour of a calibration pass.  Host-only arithmetic; pmp_fingerprint_tensors needs no context and no GPU. */
+int pmp_weights_fingerprint(const pmp_ctx *ctx, int net_id, int qp, uint64_t *out);
+int pmp_fingerprint_tensors(const float *blob, const pmp_tensor_desc *descs, int ndesc, uint64_t *out);
 
 /* ---- inference: inference_pre_QBD (Metrics.py:387-419).  block_u/block_v are ignored for PMP_LUMA. --- */
 int pmp_infer(pmp_ctx *ctx, int comp, int qp, const uint8_t *block_y, const uint8_t *block_u,

@@ -46,6 +46,8 @@ SIGNATURES = {
     "pmp_load_weights": (_I, [_VP, _I, _I, _VP, C.POINTER(TensorDesc), _I]),
     "pmp_load_weights_file": (_I, [_VP, _I, _I, C.c_char_p]),
     "pmp_has_weights": (_I, [_VP, _I, _I]),
+    "pmp_weights_fingerprint": (_I, [_VP, _I, _I, C.POINTER(C.c_uint64)]),
+    "pmp_fingerprint_tensors": (_I, [_VP, C.POINTER(TensorDesc), _I, C.POINTER(C.c_uint64)]),
     "pmp_debug_read_weights_file": (_I, [C.c_char_p, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I64), C.POINTER(C.c_double)]),
     "pmp_infer": (_I, [_VP, _I, _I, _VP, _VP, _VP, _I64, _VP, _VP, _VP]),
     "pmp_infer_device": (_I, [_VP, _I, _I, _VP, _VP, _VP, _I64, _VP, _VP, _VP]),

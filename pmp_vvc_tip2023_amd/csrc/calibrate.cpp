@@ -18,7 +18,7 @@ namespace pmp {
 // white, 1- and 2-pixel checkerboards, stripes, step edges, white noise, and smooth random content of three grain sizes (the kind
 // recipe R makes).  Deterministic (a 64-bit LCG), so every context, rank and run derives the same exponents from the same weights.
 constexpr int PMP_CAL_BLOCKS = 32;
-constexpr int PMP_CAL_ATT_MAX_EXP = 6;      // largest exponent of an attention segment (its input, built from O(1) logits, must stay out of fp16's subnormals)
+constexpr int PMP_CAL_ATT_MAX_EXP = PMP_ACT_EXP_ATT_MAX;   // 6: largest exponent of an attention segment (its input, built from O(1) logits, must stay out of fp16's subnormals); pmp_hostonly.h - the .pmpw reader applies the same bounds to a manifest's exponents
 constexpr int PMP_CAL_PASS = 16;            // blocks per calibration pass (its private workspace: 44 MB)
 constexpr int PMP_CAL_TARGET_EXP = 12;      // a segment whose calibration maximum exceeds 2^12 is scaled down to it: 16x headroom to 65504
 
@@ -143,7 +143,7 @@ int calibrate_mtt(pmp_ctx *c, bool luma, NetWeights &wq, NetWeights &wb)
         const float m = seg_max[sg];
         if (!(m == m) || std::isinf(m)) continue;
         int ex = 0;
-        while (ex < 60 && m > std::ldexp(1.f, PMP_CAL_TARGET_EXP + ex)) ++ex;
+        while (ex < PMP_ACT_EXP_MAX && m > std::ldexp(1.f, PMP_CAL_TARGET_EXP + ex)) ++ex;
         // An attention segment BEGINS with its smallest tensor - three channels of logits, O(1) - and one exponent serves the whole segment:
         // beyond 2^-6 that input would sink into fp16's subnormals (measured: a 2^18 gain inside an attention trunk, fully absorbed, cost
         // 1e-2 on the logits).  Capped there; a trunk that still leaves the range raises the flag and the call re-runs on fp32.
@@ -152,6 +152,9 @@ int calibrate_mtt(pmp_ctx *c, bool luma, NetWeights &wq, NetWeights &wb)
     }
     if ((rc = set_activation_scales(c, wb, exps)) != PMP_OK) return rc;
     wb.calibrated = true;
+    wb.act_from_file = false;
+    wb.act_fp_known = true;          // these exponents belong to exactly this QT partner
+    wb.act_qt_fp = wq.fp;
     return PMP_OK;
 }
 
@@ -165,6 +168,22 @@ int calibrate_if_ready(pmp_ctx *c, int net_id, int qp)
     NetWeights *wq = find_net(c, luma ? PMP_NET_LUMA_Q : PMP_NET_CHROMA_Q, qp), *wb = find_net(c, luma ? PMP_NET_LUMA_MSBD : PMP_NET_CHROMA_MSBD, qp);
     if (!wq || !wb || wb->calibrated) return PMP_OK;
     return calibrate_mtt(c, luma, *wq, *wb);
+}
+
+// The exponents of an MTT net depend on its QT partner too - the raw QT logits feed the MTT stem and both attention inputs
+// (Model_QBD.py:130,140,147).  Called when a QT net has been (re)loaded: exponents that were calibrated with, or whose manifest names,
+// ANOTHER QT net are dropped (overflow would only cost fp32 re-runs; underflow would be silent), so that calibrate_if_ready - or the lazy
+// check at the first f16x3 call - derives them again.  Exponents from a manifest without fingerprints (files written before round 6) are
+// trusted at the moment of loading only: a QT net that arrives later cannot be checked against them.
+void qt_partner_changed(pmp_ctx *c, int qt_net_id, int qp)
+{
+    const bool luma = qt_net_id == PMP_NET_LUMA_Q;
+    NetWeights *wq = find_net(c, qt_net_id, qp), *wb = find_net(c, luma ? PMP_NET_LUMA_MSBD : PMP_NET_CHROMA_MSBD, qp);
+    if (!wq || !wb || !wb->calibrated) return;
+    if (wb->act_fp_known && wb->act_qt_fp == wq->fp) return;
+    wb->calibrated = false;
+    wb->act_from_file = false;
+    wb->act_fp_known = false;
 }
 
 }  // namespace pmp

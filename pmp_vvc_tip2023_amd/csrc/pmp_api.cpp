@@ -550,7 +550,17 @@ int pmp_load_weights(pmp_ctx *c, int net_id, int qp, const float *blob, const pm
     int rc = pmp_has_weights(c, net_id, qp) ? settle(c) : PMP_OK;
     if (rc != PMP_OK) return rc;
     if ((rc = load_net_weights(c, net_id, qp, blob, descs, ndesc)) != PMP_OK) return rc;
+    if (net_id == PMP_NET_LUMA_Q || net_id == PMP_NET_CHROMA_Q) qt_partner_changed(c, net_id, qp);
     return calibrate_if_ready(c, net_id, qp);
+}
+
+int pmp_weights_fingerprint(const pmp_ctx *c, int net_id, int qp, uint64_t *out)
+{
+    if (!c || !out) return set_err(nullptr, PMP_E_INVALID, "pmp_weights_fingerprint: null argument");
+    auto it = c->nets.find(net_id * 100 + qp);
+    if (it == c->nets.end() || !it->second.loaded) return PMP_E_NOWEIGHTS;
+    *out = it->second.fp;
+    return PMP_OK;
 }
 
 int pmp_load_weights_file(pmp_ctx *c, int net_id, int qp, const char *path)
@@ -571,13 +581,24 @@ int pmp_load_weights_file(pmp_ctx *c, int net_id, int qp, const char *path)
     }
     if (pmp_has_weights(c, net_id, qp) && (rc = settle(c)) != PMP_OK) return rc;   // see pmp_load_weights
     if ((rc = load_net_weights(c, net_id, qp, wf.payload.data(), descs.data(), (int)descs.size())) != PMP_OK) return rc;
+    if (net_id == PMP_NET_LUMA_Q || net_id == PMP_NET_CHROMA_Q) qt_partner_changed(c, net_id, qp);
     if (wf.act_exp.size() == 5 && (net_id == PMP_NET_LUMA_MSBD || net_id == PMP_NET_CHROMA_MSBD)) {
-        // the file carries its activation-scale exponents (the conversion tool calibrated once): nothing to run here
+        // The file carries its activation-scale exponents (tools/calibrate_pmpw.py calibrated once): nothing to run here - IF they belong
+        // to these tensors.  The reader has bounded them (pmpw_file.cpp); "act_fp" says which tensors and which QT partner they were
+        // calibrated on: a manifest whose fingerprints do not match (tensors edited, the QT net replaced since) is stale, and its
+        // exponents are ignored in favour of a calibration pass.  A QT partner that is not loaded yet is checked when it arrives.
         NetWeights *nw = find_net(c, net_id, qp);
-        if ((rc = set_activation_scales(c, *nw, wf.act_exp.data())) != PMP_OK) return rc;
-        nw->calibrated = true;
-        nw->cal_names.clear(); nw->cal_seg.clear(); nw->cal_amax.clear();
-        return PMP_OK;
+        NetWeights *wq = find_net(c, net_id == PMP_NET_LUMA_MSBD ? PMP_NET_LUMA_Q : PMP_NET_CHROMA_Q, qp);
+        const bool stale = wf.have_fp && (wf.act_mtt_fp != nw->fp || (wq && wf.act_qt_fp != wq->fp));
+        if (!stale) {
+            if ((rc = set_activation_scales(c, *nw, wf.act_exp.data())) != PMP_OK) return rc;
+            nw->calibrated = true;
+            nw->act_from_file = true;
+            nw->act_fp_known = wf.have_fp;
+            nw->act_qt_fp = wf.act_qt_fp;
+            nw->cal_names.clear(); nw->cal_seg.clear(); nw->cal_amax.clear();
+            return PMP_OK;
+        }
     }
     return calibrate_if_ready(c, net_id, qp);
 }

@@ -59,6 +59,9 @@ struct NetWeights {
     // the net is first used on the f16x3 datapath (calibrate.cpp: calibrate_mtt); all zero = the arithmetic of a net without scales, bit for bit.
     int act_exp[5] = {0, 0, 0, 0, 0};
     bool calibrated = false;
+    uint64_t fp = 0;                                   // fingerprint_tensors() of `host` (pmp_weights_fingerprint)
+    bool act_from_file = false;                        // the exponents came from a manifest ...
+    bool act_fp_known = false; uint64_t act_qt_fp = 0; // ... that says which QT partner they were calibrated with
     float *stem_b_h = nullptr;                         // f16x3: stem biases * 2^-act_exp[0]
     float *head_w_h[3] = {nullptr, nullptr, nullptr};  // f16x3: head weights * 2^act_exp[{0, 2, 4}]
     std::vector<std::string> cal_names;                // calibration record: tensors in launch order ...
@@ -189,6 +192,7 @@ int settle(pmp_ctx *c);                                             // everythin
 
 // calibrate.cpp
 int calibrate_mtt(pmp_ctx *c, bool luma, NetWeights &wq, NetWeights &wb);
+void qt_partner_changed(pmp_ctx *c, int qt_net_id, int qp);         // a QT net was (re)loaded: its MTT partner's exponents may be stale
 int calibrate_if_ready(pmp_ctx *c, int net_id, int qp);             // a (QT, MTT) pair that has just become complete, on the f16x3 datapath
 
 // nets.cpp: forward graphs on device pointers (n <= chunk); all launches go to c->stream.

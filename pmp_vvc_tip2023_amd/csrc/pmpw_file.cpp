@@ -2,12 +2,14 @@
 //
 //     "PMPW1\n" | u32 little-endian JSON length | JSON manifest | raw little-endian float32 payload
 //     manifest = {"net": "Luma_Q", "qp": 22, "source": "...", "tensors": [{"name": "...", "shape": [..], "offset": N}, ...]
-//                 [, "act_exp": [e0, e1, e2, e3, e4]]}      (MTT nets: f16x3 activation-scale exponents, then no calibration at load)
+//                 [, "act_exp": [e0, e1, e2, e3, e4]        (MTT nets: f16x3 activation-scale exponents, then no calibration at load)
+//                  , "act_fp": ["<16 hex: this net's tensors>", "<16 hex: the QT partner's>"]]}   (what the exponents were calibrated on)
 //
 // so that a host without Python (the in-process VTM hook) can feed pmp_load_weights.  Counterpart of
 // load_pretrain_model (Inference_QBD.py:28-46).  Pure host code (no HIP): part of the sanitizer test library too.
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 
 #include "pmp_hostonly.h"
@@ -109,7 +111,12 @@ int read_pmpw(const char *path, WeightFile &wf)
                 if (!s.lit(']')) {
                     for (;;) {
                         long long v;
-                        if (!s.integer(v) || v < 0 || v > 60 || wf.act_exp.size() >= 5) return bad("act_exp entry (five integers 0..60)");
+                        // bounded like the calibration's own choices (calibrate.cpp): a trunk segment up to 2^-30, an attention segment up to 2^-6
+                        // (its O(1) input would sink into fp16's subnormals beyond that and silently lose the logits; overflow has the range
+                        // guard behind it, underflow has nothing)
+                        const size_t sg = wf.act_exp.size();
+                        if (!s.integer(v) || v < 0 || sg >= 5 || v > ((sg == 1 || sg == 3) ? PMP_ACT_EXP_ATT_MAX : PMP_ACT_EXP_MAX))
+                            return bad("act_exp entry (five integers: 0..30 for segments 0, 2, 4; 0..6 for the attention segments 1, 3)");
                         wf.act_exp.push_back((int)v);
                         if (s.lit(',')) continue;
                         if (!s.lit(']')) return bad("act_exp end");
@@ -117,6 +124,22 @@ int read_pmpw(const char *path, WeightFile &wf)
                     }
                 }
                 if (wf.act_exp.size() != 5) return bad("act_exp needs five entries");
+            }
+            else if (key == "act_fp") {    // optional: what "act_exp" was calibrated on - [this net's fingerprint, its QT partner's], 16 hex digits each
+                std::string a, b;
+                if (!s.lit('[') || !s.str(a) || !s.lit(',') || !s.str(b) || !s.lit(']')) return bad("act_fp is not an array of two strings");
+                auto hex = [](const std::string &h, uint64_t &out) {
+                    if (h.size() != 16) return false;
+                    out = 0;
+                    for (char ch : h) {
+                        const int d = ch >= '0' && ch <= '9' ? ch - '0' : ch >= 'a' && ch <= 'f' ? ch - 'a' + 10 : -1;
+                        if (d < 0) return false;
+                        out = (out << 4) | (uint64_t)d;
+                    }
+                    return true;
+                };
+                if (!hex(a, wf.act_mtt_fp) || !hex(b, wf.act_qt_fp)) return bad("act_fp entry (16 lower-case hex digits)");
+                wf.have_fp = true;
             }
             else if (key == "tensors") {
                 have_tensors = true;
@@ -170,6 +193,34 @@ int read_pmpw(const char *path, WeightFile &wf)
     return PMP_OK;
 }
 
+// Fingerprint of a tensor set, independent of the order and layout the caller hands it over in: tensors sorted by name; per tensor
+// FNV-1a over the name, the shape folded in, then a position-weighted sum of the float BIT patterns (vectorisable: weights.py computes
+// the same number with numpy).  Not cryptographic - it catches the stale file, not the adversary.
+uint64_t fingerprint_tensors(const float *blob, const pmp_tensor_desc *descs, int ndesc)
+{
+    constexpr uint64_t P = 0x100000001b3ull;
+    std::vector<int> order(ndesc);
+    for (int i = 0; i < ndesc; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return strcmp(descs[a].name, descs[b].name) < 0; });
+    uint64_t fp = 0xcbf29ce484222325ull;
+    for (int i : order) {
+        uint64_t h = 0xcbf29ce484222325ull;
+        for (const char *c = descs[i].name; *c; ++c) h = (h ^ (uint64_t)(unsigned char)*c) * P;
+        uint64_t cnt = 1;
+        for (int j = 0; j < descs[i].ndim; ++j) { h = (h ^ (uint64_t)descs[i].shape[j]) * P; cnt *= (uint64_t)descs[i].shape[j]; }
+        const float *w = blob + descs[i].offset;
+        uint64_t sum = 0;
+        for (uint64_t k = 0; k < cnt; ++k) {
+            uint32_t bits;
+            memcpy(&bits, w + k, 4);
+            sum += ((uint64_t)bits + 0x9E3779B97F4A7C15ull) * (2 * k + 1);
+        }
+        h = (h ^ sum) * P;
+        fp = (fp ^ h) * P;
+    }
+    return fp;
+}
+
 int net_id_of(const std::string &net)
 {
     if (net == "Luma_Q") return PMP_NET_LUMA_Q;
@@ -180,6 +231,15 @@ int net_id_of(const std::string &net)
 }
 
 }  // namespace pmp
+
+extern "C" int pmp_fingerprint_tensors(const float *blob, const pmp_tensor_desc *descs, int ndesc, uint64_t *out)
+{
+    if (!blob || !descs || ndesc <= 0 || !out) return pmp::set_err_global(PMP_E_INVALID, "pmp_fingerprint_tensors: bad arguments");
+    for (int i = 0; i < ndesc; ++i)
+        if (!descs[i].name || descs[i].ndim < 0 || descs[i].ndim > 4 || descs[i].offset < 0) return pmp::set_err_global(PMP_E_INVALID, "pmp_fingerprint_tensors: bad tensor descriptor");
+    *out = pmp::fingerprint_tensors(blob, descs, ndesc);
+    return PMP_OK;
+}
 
 extern "C" int pmp_debug_read_weights_file(const char *path, int *net_id, int *qp, int *ntensors, int64_t *nfloats, double *checksum)
 {

@@ -261,6 +261,7 @@ int load_net_weights(pmp_ctx *c, int net_id, int qp, const float *blob, const pm
         nw.host.insert(nw.host.end(), blob + descs[i].offset, blob + descs[i].offset + cnt);
     }
     for (int i = 0; i < ndesc; ++i) nw.descs[i].name = nw.names[i].c_str();
+    nw.fp = fingerprint_tensors(nw.host.data(), nw.descs.data(), ndesc);
     Blob b{nw.host.data(), nw.descs.data(), ndesc};
     const int rc = build_net(c, net_id, b, nw, (1u << c->precision) | abl_pack_mask(c));
     if (rc != PMP_OK) { free_net_weights(nw); return rc; }

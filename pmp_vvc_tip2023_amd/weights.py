@@ -5,7 +5,8 @@ prefixes (trained_models/*.pkl; loader Inference_QBD.py:28-46).  The product's o
 
     b"PMPW1\\n" | u32 little-endian JSON length | JSON manifest | raw little-endian float32 payload
 
-manifest = {"net": "Luma_Q", "qp": 22, "source": ..., "tensors": [{"name", "shape", "offset"(floats)}][, "act_exp": [5 ints]]}.
+manifest = {"net": "Luma_Q", "qp": 22, "source": ..., "tensors": [{"name", "shape", "offset"(floats)}]
+            [, "act_exp": [5 ints], "act_fp": [fingerprint of these tensors, of the QT partner's: 16 hex digits each]]}.
 Tensor names/shapes are the reference's state_dict names with `module.` stripped (OIHW convs, 1-D biases).
 `.pmpw` needs only numpy; `.pkl` import needs torch (PyTorch is used for weight loading only).
 """
@@ -20,9 +21,35 @@ NETS = ("Luma_Q", "Luma_MSBD", "Chroma_Q", "Chroma_MSBD")
 QPS = (22, 27, 32, 37)
 
 
-def save_pmpw(path, net, qp, tensors, source="", act_exp=None):
+ACT_EXP_MAX, ACT_EXP_ATT_MAX = 30, 6      # csrc/pmp_hostonly.h: bounds of a manifest's exponents (trunk segments 0, 2, 4 / attention segments 1, 3)
+_M64 = (1 << 64) - 1
+
+
+def fingerprint(tensors):
+    """csrc/pmpw_file.cpp: fingerprint_tensors - the same 64-bit number from {name: ndarray}: tensors sorted by name; FNV-1a over the name,
+    the shape folded in, a position-weighted sum of the float32 bit patterns."""
+    P = 0x100000001b3
+    fp = 0xcbf29ce484222325
+    for name in sorted(tensors, key=lambda k: k.encode()):
+        a = np.ascontiguousarray(tensors[name], dtype="<f4")
+        h = 0xcbf29ce484222325
+        for ch in name.encode():
+            h = ((h ^ ch) * P) & _M64
+        for d in a.shape:
+            h = ((h ^ int(d)) * P) & _M64
+        bits = a.reshape(-1).view("<u4").astype(np.uint64)
+        with np.errstate(over="ignore"):
+            s = int(((bits + np.uint64(0x9E3779B97F4A7C15)) * (np.arange(bits.size, dtype=np.uint64) * np.uint64(2) + np.uint64(1))).sum(dtype=np.uint64))
+        h = ((h ^ s) * P) & _M64
+        fp = ((fp ^ h) * P) & _M64
+    return fp
+
+
+def save_pmpw(path, net, qp, tensors, source="", act_exp=None, qt_partner=None):
     """tensors: ordered {name: float32 ndarray}.  act_exp (MTT nets, optional): the five f16x3 activation-scale exponents a calibration on
-    the target GPU chose (Engine.activation_report(...)["exps"]); a file that carries them is loaded without a calibration pass."""
+    the target GPU chose (Engine.activation_report(...)["exps"]); a file that carries them is loaded without a calibration pass.
+    qt_partner (with act_exp): the QT net's tensors the calibration ran with - their fingerprint and this net's go into "act_fp", and the
+    library ignores the exponents when either does not match what is loaded (a stale file)."""
     entries, off = [], 0
     for name, a in tensors.items():
         a = np.ascontiguousarray(a, dtype="<f4")
@@ -30,9 +57,11 @@ def save_pmpw(path, net, qp, tensors, source="", act_exp=None):
         off += a.size
     man = {"net": net, "qp": int(qp), "source": source, "tensors": entries}
     if act_exp is not None:
-        if len(act_exp) != 5 or any(int(e) < 0 or int(e) > 60 for e in act_exp):
-            raise ValueError("act_exp: five integers 0..60")
+        if len(act_exp) != 5 or any(int(e) < 0 or int(e) > (ACT_EXP_ATT_MAX if i in (1, 3) else ACT_EXP_MAX) for i, e in enumerate(act_exp)):
+            raise ValueError("act_exp: five integers, 0..%d for segments 0, 2, 4 and 0..%d for the attention segments 1, 3" % (ACT_EXP_MAX, ACT_EXP_ATT_MAX))
         man["act_exp"] = [int(e) for e in act_exp]
+        if qt_partner is not None:
+            man["act_fp"] = ["%016x" % fingerprint(tensors), "%016x" % fingerprint(qt_partner)]
     man = json.dumps(man).encode()
     with open(path, "wb") as f:
         f.write(MAGIC)

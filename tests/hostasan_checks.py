@@ -173,12 +173,17 @@ def main():
         "act_exp_four": crafted(b'{"net":"Luma_MSBD","qp":22,"act_exp":[0,0,4,0],"tensors":[{"name":"a","shape":[4],"offset":0}]}', b"\0" * 64),
         "act_exp_six": crafted(b'{"net":"Luma_MSBD","qp":22,"act_exp":[0,0,4,0,8,1],"tensors":[{"name":"a","shape":[4],"offset":0}]}', b"\0" * 64),
         "act_exp_range": crafted(b'{"net":"Luma_MSBD","qp":22,"act_exp":[0,0,61,0,8],"tensors":[{"name":"a","shape":[4],"offset":0}]}', b"\0" * 64),
+        "act_exp_attention_over_6": crafted(b'{"net":"Luma_MSBD","qp":22,"act_exp":[0,7,4,0,8],"tensors":[{"name":"a","shape":[4],"offset":0}]}', b"\0" * 64),
+        "act_exp_trunk_over_30": crafted(b'{"net":"Luma_MSBD","qp":22,"act_exp":[0,0,4,0,31],"tensors":[{"name":"a","shape":[4],"offset":0}]}', b"\0" * 64),
+        "act_fp_short": crafted(b'{"net":"Luma_MSBD","qp":22,"act_exp":[0,0,4,0,8],"act_fp":["0123","0123456789abcdef"],"tensors":[{"name":"a","shape":[4],"offset":0}]}', b"\0" * 64),
+        "act_fp_not_hex": crafted(b'{"net":"Luma_MSBD","qp":22,"act_fp":["0123456789abcdeg","0123456789abcdef"],"tensors":[{"name":"a","shape":[4],"offset":0}]}', b"\0" * 64),
+        "act_fp_one": crafted(b'{"net":"Luma_MSBD","qp":22,"act_fp":["0123456789abcdef"],"tensors":[{"name":"a","shape":[4],"offset":0}]}', b"\0" * 64),
         "act_exp_negative": crafted(b'{"net":"Luma_MSBD","qp":22,"act_exp":[0,0,-1,0,8],"tensors":[{"name":"a","shape":[4],"offset":0}]}', b"\0" * 64),
         "act_exp_not_array": crafted(b'{"net":"Luma_MSBD","qp":22,"act_exp":4,"tensors":[{"name":"a","shape":[4],"offset":0}]}', b"\0" * 64),
         "act_exp_unterminated": crafted(b'{"net":"Luma_MSBD","qp":22,"act_exp":[0,0,4,0,8'),
     })
     ok2 = os.path.join(tmp, "act_exp_ok.pmpw")
-    open(ok2, "wb").write(crafted(b'{"net":"Luma_MSBD","qp":22,"act_exp":[0, 0, 4, 0, 8],"tensors":[{"name":"a","shape":[4],"offset":0}]}', b"\0" * 64))
+    open(ok2, "wb").write(crafted(b'{"net":"Luma_MSBD","qp":22,"act_exp":[30, 6, 4, 0, 8],"act_fp":["0123456789abcdef", "fedcba9876543210"],"tensors":[{"name":"a","shape":[4],"offset":0}]}', b"\0" * 64))
     assert lib.pmp_debug_read_weights_file(ok2.encode(), None, None, None, None, None) == 0
     ok = os.path.join(tmp, "edge_ok.pmpw")       # the last four floats of the payload: accepted
     open(ok, "wb").write(crafted(b'{"net":"Luma_Q","qp":22,"tensors":[{"name":"a","shape":[4],"offset":12}]}', b"\0" * 64))

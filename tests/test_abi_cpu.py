@@ -232,6 +232,43 @@ def test_pmpw_container_reader_matches_python(lib, tmp_path):
     assert lib.pmp_debug_read_weights_file(str(tmp_path / "nope.pmpw").encode(), None, None, None, None, None) == -4
 
 
+def test_weight_fingerprint_python_equals_library(lib):
+    """weights.fingerprint (numpy) == pmp_fingerprint_tensors (pmpw_file.cpp), independent of the order and layout the tensors are handed
+    over in, sensitive to one changed bit, to a shape and to a name: what ties a manifest's "act_exp" to its nets (include/pmp.h)."""
+    from pmp_vvc_tip2023_amd import synth, weights as W
+
+    def lib_fp(tensors, order=None, gap=0):
+        names = list(tensors) if order is None else order
+        descs = (_lib.TensorDesc * len(names))()
+        chunks, off = [], 0
+        for i, k in enumerate(names):
+            a = np.ascontiguousarray(tensors[k], np.float32)
+            descs[i].name = k.encode(); descs[i].ndim = a.ndim
+            for j, d in enumerate(a.shape):
+                descs[i].shape[j] = d
+            off += gap
+            chunks.append(np.zeros(gap, np.float32)); chunks.append(a.reshape(-1))
+            descs[i].offset = off
+            off += a.size
+        blob = np.concatenate(chunks)
+        out = C.c_uint64()
+        assert lib.pmp_fingerprint_tensors(blob.ctypes.data_as(C.c_void_p), descs, len(names), C.byref(out)) == 0
+        return out.value
+    w = synth.synth_msbd_weights("Chroma", 27)
+    fp = W.fingerprint(w)
+    assert fp == lib_fp(w) == lib_fp(w, order=list(w)[::-1], gap=3) and fp == W.fingerprint(dict(reversed(list(w.items()))))
+    for fn in ("Luma_Q_22.pmpw", "Chroma_Q_37.pmpw"):
+        t = W.load_pmpw(os.path.join(W.default_weight_dir(), fn))[1]
+        assert W.fingerprint(t) == lib_fp(t)
+    k0 = list(w)[5]
+    w2 = dict(w); a = w[k0].copy(); a.reshape(-1).view(np.uint32)[-1] ^= 1; w2[k0] = a                 # one mantissa bit
+    w3 = dict(w); w3[k0] = w[k0].reshape(w[k0].shape[::-1]) if w[k0].ndim > 1 else w[k0].reshape(1, -1)   # same bytes, another shape
+    w4 = {(k + "x" if k == k0 else k): v for k, v in w.items()}
+    w5 = dict(w); b = w[k0].copy().reshape(-1); b[[0, 1]] = b[[1, 0]]; w5[k0] = b.reshape(w[k0].shape)     # two values swapped
+    fps = {fp, W.fingerprint(w2), W.fingerprint(w3), W.fingerprint(w4), W.fingerprint(w5)}
+    assert len(fps) == 5 and W.fingerprint(w2) == lib_fp(w2) and W.fingerprint(w5) == lib_fp(w5)
+
+
 def test_tracked_tree_holds_no_binaries():
     """Round 4 left clang-offload-bundler extractions (ELF code objects) in the package directory: nothing tracked under the product, the
     boundary or the oracle may be an ELF / archive / code-object file (built artefacts travel to the GPU box untracked, .gitignore)."""

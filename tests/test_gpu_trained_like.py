@@ -246,6 +246,71 @@ def test_manifest_exponents_skip_the_calibration(tmp_path):
         assert np.array_equal(p, q)
 
 
+def test_stale_manifest_exponents_are_ignored_and_a_new_qt_partner_recalibrates(tmp_path):
+    """nothing tied a manifest's "act_exp" to the tensors it was calibrated on.  Now "act_fp" does (fingerprints of the MTT
+    tensors and of the QT partner): a manifest written for ANOTHER QT net, or whose tensors were edited afterwards, is ignored in favour
+    of a calibration pass - in both loading orders - while the matching one is still taken without a pass; and replacing only the QT net
+    of a calibrated pair drops the exponents that were derived with the old one (overflow would merely cost fp32 re-runs; underflow
+    would be silent)."""
+    import ctypes as C
+    import shutil
+    from pmp_vvc_tip2023_amd import _lib, engine, synth, weights as W
+    w = synth.trained_like_msbd_weights("Luma", 22, trunk_gain=64.0)
+    wq22, _ = W.load_net_weights("Luma_Q", 22)
+    wq37, _ = W.load_net_weights("Luma_Q", 37)
+    e = engine.Engine(0)
+    try:
+        e.load("Luma", 22, msbd_weights=w)
+        good = e.activation_report("Luma", 22)["exps"]
+        fp = C.c_uint64()
+        assert e.lib.pmp_weights_fingerprint(e.h, _lib.NET_IDS["Luma_MSBD"], 22, C.byref(fp)) == 0 and fp.value == W.fingerprint(w)
+        assert e.lib.pmp_weights_fingerprint(e.h, _lib.NET_IDS["Luma_Q"], 22, C.byref(fp)) == 0 and fp.value == W.fingerprint(wq22)
+        assert e.lib.pmp_weights_fingerprint(e.h, _lib.NET_IDS["Luma_Q"], 27, C.byref(fp)) == -3
+        # the pair with QP37's QT tensors standing in for QP22's: different logits into the MTT stem and attention inputs
+        e.load_pretrain_model("Luma_Q", 22, wq37)
+        rep37 = e.activation_report("Luma", 22)
+        assert len(rep37["tensors"]) == 49, "replacing the QT net did not re-calibrate its MTT partner"
+        e.load_pretrain_model("Luma_Q", 22, wq37)                    # the same tensors again: nothing to redo
+        assert e.activation_report("Luma", 22)["exps"] == rep37["exps"]
+    finally:
+        e.close()
+    wrong = [min(x + 3, 30) for x in good[:1]] + [0, good[2] + 2, 0, good[4] + 1]     # recognisably not what a calibration chooses
+    shutil.copy(os.path.join(W.default_weight_dir(), "Luma_Q_22.pmpw"), tmp_path)
+    bd = str(tmp_path / "Luma_BD_22.pmpw")
+    for order in ("qt_first", "mtt_first"):
+        for case, qt_partner, expect_file in (("matching", wq22, True), ("other_qt", wq37, False)):
+            W.save_pmpw(bd, "Luma_MSBD", 22, w, source="test", act_exp=wrong, qt_partner=qt_partner)
+            e2 = engine.Engine(0, weight_dir=str(tmp_path))
+            try:
+                nets = [("Luma_Q", str(tmp_path / "Luma_Q_22.pmpw")), ("Luma_MSBD", bd)]
+                for net, path in (nets if order == "qt_first" else nets[::-1]):
+                    assert e2.lib.pmp_load_weights_file(e2.h, _lib.NET_IDS[net], 22, path.encode()) == 0, e2.lib.pmp_last_error(e2.h)
+                rep = e2.activation_report("Luma", 22)
+                if expect_file:
+                    assert rep["exps"] == wrong and rep["tensors"] == [], (order, case)
+                else:
+                    assert rep["exps"] == good and len(rep["tensors"]) == 49, (order, case, rep["exps"])
+            finally:
+                e2.close()
+    # tensors edited after the manifest was written: its own fingerprint no longer matches
+    man, tens = W.load_pmpw(bd)
+    W.save_pmpw(bd, "Luma_MSBD", 22, w, source="test", act_exp=wrong, qt_partner=wq22)
+    raw = bytearray(open(bd, "rb").read())
+    raw[-4:] = np.float32(0.125).tobytes()                          # the last float of the payload
+    open(bd, "wb").write(bytes(raw))
+    e3 = engine.Engine(0, weight_dir=str(tmp_path))
+    try:
+        e3.load("Luma", 22)
+        rep = e3.activation_report("Luma", 22)
+        assert rep["exps"] != wrong and len(rep["tensors"]) == 49
+    finally:
+        e3.close()
+    # exponents beyond the reader's bounds never reach the kernels (attention segment > 6; trunk segment > 30)
+    for bad in ([0, 7, 0, 0, 0], [31, 0, 0, 0, 0]):
+        with pytest.raises(ValueError):
+            W.save_pmpw(bd, "Luma_MSBD", 22, w, act_exp=bad)
+
+
 def test_calibrate_pmpw_tool_writes_the_exponents(tmp_path):
     """tools/calibrate_pmpw.py on a model directory (real QT files + trained-like MTT files without exponents): every MTT file comes back
     with "act_exp" in its manifest, equal to what a calibrating load reports, and with its tensors untouched."""
@@ -268,5 +333,7 @@ def test_calibrate_pmpw_tool_writes_the_exponents(tmp_path):
             assert list(tens) == list(ref) and all(np.array_equal(tens[k], ref[k]) for k in ref)
             e.load(comp, qp, msbd_weights=ref)                     # a calibrating load of the same tensors
             assert man["act_exp"] == e.activation_report(comp, qp)["exps"]
+            wq, _ = W.load_net_weights(comp + "_Q", qp)
+            assert man["act_fp"] == ["%016x" % W.fingerprint(ref), "%016x" % W.fingerprint(wq)]
     finally:
         e.close()
