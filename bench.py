@@ -43,6 +43,37 @@ PEAK_NOTE = {"f16x3": "fp16 dense MFMA peak 2500 TFLOP/s / 3 products per fp32-a
                        "(register-resident bf16 loop on this pool sustains 1925 TFLOP/s at 1.97 GHz = 320.9 per fp32 product, "
                        "profiles/r01_mfma_peak_microbench.txt)"}
 DOMINANT = "conv_mfma_3x3_c64"                               # 3x3 64->64 convs: 57.8 % of the MTT-net FLOPs
+KERNEL_SOURCE = {"f16x3": "conv_f16x3.hip", "bf16x6": "conv_bf16x6.hip", "fp32": "conv_mfma.hip"}   # the dominant class's kernel file per datapath
+
+
+def pmc_traffic(precision, blocks_per_launch):
+    """HBM bytes per launch of the dominant kernel from the committed PMC record (profiles/pmc_traffic.json, tools/make_traffic.py) -
+    but only if that record was taken on THIS build of the kernel: the record carries the sha256 of the kernel source it was measured
+    on, and a kernel file that has changed since gets `traffic: null` with the reason instead of somebody else's bytes."""
+    import hashlib
+    tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        tj = json.load(open(tp))
+    except Exception as e:      # noqa: BLE001
+        return None, "profiles/pmc_traffic.json not readable (%s)" % e
+    key = DOMINANT + ":" + precision
+    if tj.get(key) is None:
+        return None, "profiles/pmc_traffic.json holds no PMC record for the %s datapath" % precision
+    build = tj.get("_build:" + precision)
+    src = os.path.join(ROOT, "pmp_vvc_tip2023_amd", "csrc", KERNEL_SOURCE[precision])
+    try:
+        sha = hashlib.sha256(open(src, "rb").read()).hexdigest()
+    except OSError:
+        sha = None
+    if not build or not build.get("kernel_sha256"):
+        return None, "the PMC record of the %s datapath carries no build stamp (taken before round 6): not attributed to this build" % precision
+    if sha != build["kernel_sha256"]:
+        return None, ("the PMC record was taken on another build of %s (sha256 %s..., git %s; this run: %s...): not attributed to this build"
+                      % (KERNEL_SOURCE[precision], build["kernel_sha256"][:12], (build.get("git_head") or "?")[:10], (sha or "unreadable")[:12]))
+    scale = blocks_per_launch / float(tj.get("_blocks_per_launch:" + precision, blocks_per_launch))
+    return round(tj[key] * scale), ("profiles/pmc_traffic.json: rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE; %s) of THIS kernel build "
+                                    "(%s sha256 %s..., recorded at git %s), scaled to the blocks per launch; not collected in this run"
+                                    % (build.get("pmc_summary", "?"), KERNEL_SOURCE[precision], sha[:12], (build.get("git_head") or "?")[:10]))
 
 
 def log(*a):
@@ -166,17 +197,32 @@ def cpu_all_cores(threads, ncpu, seed, s_per_block):
     budget_s = 15.0
     blocks = max(16, min(1024, int(2 * budget_s / max(s_per_block, 1e-3)) // 16 * 16))
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    import tempfile
+    import threading
+    errs = [tempfile.TemporaryFile(mode="w+") for _ in range(procs_n)]      # a worker's stderr: its tail goes to the log if it fails
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", "%d,%d,%d" % (blocks, seed + 100 + i, threads)],
-                              stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True) for i in range(procs_n)]
+                              stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=errs[i], env=env, text=True) for i in range(procs_n)]
+
+    def line(p, deadline_s, what):
+        """One line of a worker's stdout, or an error once the deadline has passed (a reader thread: a hung worker must not hang the bench)."""
+        got = []
+        th = threading.Thread(target=lambda: got.append(p.stdout.readline()), daemon=True)
+        th.start()
+        th.join(deadline_s)
+        if th.is_alive() or not got:
+            raise RuntimeError("a CPU worker did not %s within %g s" % (what, deadline_s))
+        return got[0]
     try:
-        for p in procs:
-            if p.stdout.readline().strip() != "ready":
+        t_up = time.time()
+        for p in procs:      # import torch + oneDNN warm-up under a CPU quota shared by all workers: minutes at worst, not hours
+            if line(p, max(10.0, 300.0 - (time.time() - t_up)), "come up").strip() != "ready":
                 raise RuntimeError("a CPU worker did not come up")
         for p in procs:
             p.stdin.write("go %g\n" % budget_s); p.stdin.flush()
         wins = []
-        for p in procs:
-            tok = p.stdout.readline().split()
+        t_go = time.time()
+        for p in procs:      # the budget, plus the one batch a worker finishes after it
+            tok = line(p, max(10.0, budget_s + 120.0 - (time.time() - t_go)), "finish").split()
             if len(tok) != 4 or tok[0] != "done":
                 raise RuntimeError("a CPU worker died")
             wins.append((float(tok[1]), float(tok[2]), int(tok[3])))
@@ -187,6 +233,11 @@ def cpu_all_cores(threads, ncpu, seed, s_per_block):
             if p.poll() is None:
                 p.kill()
         log("cpu_baseline: whole-host leg failed: %s" % e)
+        for i, f in enumerate(errs):
+            f.seek(0)
+            tail = f.read()[-600:].strip()
+            if tail:
+                log("cpu_baseline: worker %d stderr tail: %s" % (i, tail))
         return {"error": str(e)}
     wall = max(w[1] for w in wins) - min(w[0] for w in wins)
     total = sum(w[2] for w in wins)
@@ -201,14 +252,16 @@ def cpu_all_cores(threads, ncpu, seed, s_per_block):
 
 
 def trained_like_extra(eng, dev, n, step, timed):
-    """The same step with TRAINED-LIKE MTT weights (synth.trained_like_msbd_weights: tensors bootstrapped from the real QT-net tensors,
+    """The same step with TRAINED-LIKE MTT weights (trained_like.msbd_weights: tensors bootstrapped from the real QT-net tensors,
     trunks at 1e3, gate products at 1e4) instead of the benign uniform ones: does the headline describe a net with trained-scale
     activations?  Reports the step time, the f16x3 activation-scale exponents the library chose and the range guard's re-run count
     (must be 0: a re-run is the 2.8x slower fp32 datapath).  Also at a stress setting (trunk x 64, gates x 16)."""
     from pmp_vvc_tip2023_amd import synth
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import trained_like                  # tools/trained_like.py: test-weight data, not part of the product package
     out = {}
     for tag, gains in (("", {}), ("_stress_k64_g16", {"trunk_gain": 64.0, "gate_gain": 16.0})):
-        eng.load("Luma", 22, msbd_weights=synth.trained_like_msbd_weights("Luma", 22, **gains))
+        eng.load("Luma", 22, msbd_weights=trained_like.msbd_weights("Luma", 22, **gains))
         rep = eng.activation_report("Luma", 22)
         eng.clear_saturation()
         from pmp_vvc_tip2023_amd import sensors
@@ -228,6 +281,30 @@ def trained_like_extra(eng, dev, n, step, timed):
                    "(tests/golden/g2b_msbd_trained_like.npz pins them against the reference modules); activation_exps = per-segment power-of-two "
                    "activation scales chosen by the library's calibration pass (include/pmp.h); not used for `value`")
     return out
+
+
+def fp32_exact_extra(eng, n, step, timed):
+    """The same step on the EXACT-arithmetic datapath (PMP_PRECISION_F32: v_mfma_f32_16x16x4_f32, a bit-exact fmaf chain - the
+    reference's own arithmetic, and what a call costs when the f16x3 range guard re-runs it): 3 steps, with the dominant class timed by
+    events around its launches as in the headline's roofline, against the fp32 matrix peak."""
+    eng.set_precision("fp32")
+    try:
+        dt = timed(lambda: step("Luma", 22), 3)
+        names = [eng.lib.pmp_ktime_name(k).decode() for k in range(eng.lib.pmp_ktime_classes())]
+        eng.ktime_enable(1 << names.index(DOMINANT))
+        for _ in range(3):
+            step("Luma", 22)
+        launches, ms, flops = eng.ktime()[DOMINANT]
+        eng.ktime_enable(0)
+    finally:
+        eng.set_precision("f16x3")
+    tf = flops / (ms * 1e-3) / 1e12 if ms else None
+    return {"ctu_per_s": round(n / 4.0 / dt, 2), "ms_per_step": round(dt * 1e3, 3), "steps": 3, "dtype": "f32",
+            "net_tflops": round(n / dt * FLOP_PER_BLOCK["Luma"] / 1e12, 2),
+            "roofline": {"bound": "mfma", "kernel": DOMINANT, "achieved": round(tf, 2) if tf else None, "peak": PEAK_TFLOPS["fp32"], "unit": "TFLOP/s",
+                         "frac": round(tf / PEAK_TFLOPS["fp32"], 4) if tf else None, "launches": launches,
+                         "avg_launch_ms": round(ms / launches, 4) if launches else None, "peak_basis": PEAK_NOTE["fp32"]},
+            "note": "Luma QP22, the headline's blocks and weights, pmp_set_precision(PMP_PRECISION_F32); not used for `value`"}
 
 
 def measure_extras(eng, args, dev, n, y, u, v, step):
@@ -274,6 +351,7 @@ def measure_extras(eng, args, dev, n, y, u, v, step):
 
         if args.precision == "f16x3":
             out["extra"]["trained_like"] = trained_like_extra(eng, dev, n, step, timed)
+            out["extra"]["fp32_exact"] = fp32_exact_extra(eng, n, step, timed)
 
         def classes(comp):
             """hipEvent time of every kernel class over 3 steps (events around every launch: a few % slower than the untimed step)."""
@@ -489,22 +567,11 @@ def main():
     roof = None
     if launches:
         achieved = flops / (ms * 1e-3) / 1e12
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.isfile(tp):
-            try:   # bytes per launch from the PMC passes, scaled to the blocks one launch processes here
-                tj = json.load(open(tp))
-                traffic = tj.get(DOMINANT + ":" + args.precision)
-                if traffic is not None:
-                    per_launch = min(n, args.chunk if args.chunk else 4096)
-                    traffic = round(traffic * per_launch / float(tj.get("_blocks_per_launch:" + args.precision, per_launch)))
-            except Exception:
-                traffic = None
+        traffic, traffic_source = pmc_traffic(args.precision, min(n, args.chunk if args.chunk else 4096))
         peak = PEAK_TFLOPS[args.precision]
         roof = {"bound": "mfma", "kernel": DOMINANT, "achieved": round(achieved, 2), "peak": round(peak, 1),
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-                "traffic_source": "profiles/pmc_traffic.json: rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE) of this kernel build, "
-                                  "scaled to the blocks per launch; not collected in this run" if traffic is not None else None,
+                "traffic_source": traffic_source,
                 "peak_basis": PEAK_NOTE[args.precision],
                 "launches": launches, "avg_launch_ms": round(ms / launches, 4),
                 "flop_per_launch": flops / launches}

@@ -98,7 +98,9 @@ int64_t pmp_get_workspace_bytes(const pmp_ctx *ctx);
  * layers) then run beside the other's 64x64 convolutions.  Blocks are independent, so results do not depend on how a call is cut (bit-
  * identical records; tests/test_gpu_parity.py).  Measured -0.2 ... -1.2 % (luma) / -0.7 ... -1.7 % (chroma) on the 4096-block step.  Two launches share
  * the device then, so the per-launch durations of pmp_ktime_* (and of a profiler) no longer describe a kernel running alone: bench.py
- * keeps the mode off for its timed region and reports its effect beside it. */
+ * keeps the mode off for its timed region and reports its effect beside it.  At JOB level (the CLI driver on 8 x 4K frames, all eight
+ * files) the mode bought nothing - 1.702 s on, 1.701 s off (profiles/r05e_driver_bench.txt): the driver's pipeline already hides the
+ * small launches' gaps - so the driver leaves it off too (its --overlap turns it on; round 5 had it on by default). */
 int pmp_set_overlap(pmp_ctx *ctx, int on);
 
 /* Convolution datapath.  All three are fp32-accurate (EXPERIMENTS.md, precision study); results differ in the last bits only.
@@ -279,14 +281,14 @@ int pmp_ktime_get(pmp_ctx *ctx, int cls, int64_t *launches, double *ms, double *
 /* ---- measurement hook.  The product library ships ONE form of every convolution kernel - number 2 - and accepts nothing else
  *      here (PMP_E_INVALID): it has no process-wide kernel selector.  The forms that were built, parity-tested and measured slower
  *      than or equal to the shipped ones (1, 3..9; bit-identical results) and the timing-only builds (10 and above; WRONG results)
- *      exist only in the measurement library libpmp_hip_abl.so (`make abl`), where this call selects them process-wide for
- *      in-process A/B timing (tools/conv_ab.py, tools/variants_agree.py; the list is in csrc/abl/conv_f16x3.hip, the numbers in EXPERIMENTS.md). ---- */
+ *      exist only in the measurement library tools/abl/libpmp_hip_abl.so (`make -C tools/abl`), where this call selects them process-wide for
+ *      in-process A/B timing (tools/conv_ab.py, tools/variants_agree.py; the list is in tools/abl/conv_f16x3.hip, the numbers in EXPERIMENTS.md). ---- */
 int pmp_debug_set_conv_variant(int variant);
 
 /* ---- measurement hook (f16x3 datapath): run the 3x3 64->64 convolutions - 55 % of the luma step - in the Winograd F(2,3)-along-x
  *      form (conv_f16x3_wx.hip: 1.5x fewer MFMAs, fp32-equivalent logits within the 1e-3 tolerance, not bit-identical to the direct
  *      form).  It did not beat the direct kernels (EXPERIMENTS.md, profiles/r03_notes.txt), so like the other forms that lost their
- *      A/B it exists in the measurement library libpmp_hip_abl.so only (`make abl`; tools/wx_probe.py, tools/wx_ablate.py): the
+ *      A/B it exists in the measurement library tools/abl/libpmp_hip_abl.so only (`make -C tools/abl`; tools/wx_probe.py, tools/wx_ablate.py): the
  *      product library accepts on = 0 and answers PMP_E_INVALID to anything else. ---- */
 int pmp_debug_set_winograd(pmp_ctx *ctx, int on);
 

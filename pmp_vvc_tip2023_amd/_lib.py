@@ -5,7 +5,6 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpmp_hip.so")
-ABL_LIB_PATH = os.path.join(_HERE, "libpmp_hip_abl.so")            # make abl: measurement build with timing-only kernels (tools/ only)
 HOSTASAN_LIB_PATH = os.path.join(_HERE, "libpmp_hostasan.so")      # make hostasan: host-only units under ASan/UBSan (tests only)
 
 PMP_LUMA, PMP_CHROMA = 0, 1

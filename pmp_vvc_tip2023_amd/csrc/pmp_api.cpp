@@ -802,8 +802,8 @@ int pmp_debug_set_conv_variant(int variant)
     int rc;
     if (abl_set_conv_variant(variant, &rc)) return rc;
     // the product library ships ONE form of every kernel (number 2): there is no process-wide selector in it.  The A/B forms
-    // (bit-identical, measured slower or equal) and the timing-only builds live in libpmp_hip_abl.so (make abl)
-    if (variant != 2) return set_err(nullptr, PMP_E_INVALID, "pmp_debug_set_conv_variant: this library ships only the default form (2); the A/B and timing-only builds are in libpmp_hip_abl.so (make abl)");
+    // (bit-identical, measured slower or equal) and the timing-only builds live in tools/abl/libpmp_hip_abl.so (make -C tools/abl)
+    if (variant != 2) return set_err(nullptr, PMP_E_INVALID, "pmp_debug_set_conv_variant: this library ships only the default form (2); the A/B and timing-only builds are in tools/abl/libpmp_hip_abl.so (make -C tools/abl)");
     return PMP_OK;
 }
 
@@ -824,8 +824,8 @@ int pmp_debug_set_winograd(pmp_ctx *c, int on)
     int rc = settle(c);
     if (rc != PMP_OK) return rc;
     if (abl_set_winograd(c, on, &rc)) return rc;
-    // the Winograd-x kernel did not beat the direct form (profiles/r03_notes.txt): it lives in libpmp_hip_abl.so (make abl)
-    if (on) return set_err(c, PMP_E_INVALID, "pmp_debug_set_winograd: the Winograd-x form is built into libpmp_hip_abl.so only (make abl)");
+    // the Winograd-x kernel did not beat the direct form (profiles/r03_notes.txt): it lives in tools/abl/libpmp_hip_abl.so (make -C tools/abl)
+    if (on) return set_err(c, PMP_E_INVALID, "pmp_debug_set_winograd: the Winograd-x form is built into tools/abl/libpmp_hip_abl.so only (make -C tools/abl)");
     return PMP_OK;
 }
 

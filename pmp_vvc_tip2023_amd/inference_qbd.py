@@ -152,9 +152,11 @@ def build_parser():
                    help="sharded (default): every rank formats and pwrites the text of its own block rows, the ranks exchange only byte "
                         "counts; gather: RCCL gather of the records to rank 0, which writes the file alone")
     p.add_argument("--emitThreads", default=0, type=int, help="formatter / writer threads per rank (0 = cores / ranks, at most 8)")
-    p.add_argument("--noOverlap", action="store_true",
-                   help="turn the library's overlap mode off (include/pmp.h: pmp_set_overlap).  Default on: a pass of >= 1024 blocks runs as two "
-                        "chunks on two streams, so one chunk's small launches fill the gaps of the other's large ones; bit-identical files")
+    p.add_argument("--overlap", action="store_true",
+                   help="turn the library's overlap mode on (include/pmp.h: pmp_set_overlap): a pass of >= 1024 blocks runs as two chunks on "
+                        "two streams, so one chunk's small launches fill the gaps of the other's large ones; bit-identical files.  Opt-in "
+                        "(round 6): it takes 0.2-1.7 %% off a bare 4096-block step but nothing off a whole job (8 x 4K frames, all eight "
+                        "files: 1.702 s on, 1.701 s off, profiles/r05e_driver_bench.txt) and costs a second workspace")
     p.add_argument("--hostBlocks", action="store_true",
                    help="keep the cut blocks in host memory and upload them for every (component, QP) pass, as the reference "
                         "does; default: frames are uploaded once, cut on the GPU and the blocks stay device-resident")
@@ -299,7 +301,7 @@ def inference_VVC_seqs(args):
     # --strictBatch asks for it (clamped to the library's 4096-block pass; the reference accepts any value)
     eng.set_chunk(min(max(1, args.batchSize), 4096) if args.strictBatch else 4096)
     eng.set_precision(args.precision)
-    eng.set_overlap(not args.noOverlap)      # the driver has no per-launch timing to protect (bench.py keeps the mode off for its roofline leg)
+    eng.set_overlap(args.overlap)            # opt-in: measured to buy nothing at job level (see --overlap)
     device = None
     if world > 1:
         import torch

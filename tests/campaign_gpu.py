@@ -9,12 +9,15 @@ import os
 
 import numpy as np
 import pytest
+
+import conftest  # noqa: F401 - puts tools/ on sys.path
+import trained_like  # tools/trained_like.py: test-weight data (round 6: out of the product package)
 import torch
 
 TOL = 1e-3
 N = int(os.environ.get("PMP_CAMPAIGN_BLOCKS", "4096"))
 PRECISION = os.environ.get("PMP_CAMPAIGN_PRECISION", "f16x3")      # f16x3 (default datapath) | bf16x6 | fp32
-MTT_WEIGHTS = os.environ.get("PMP_CAMPAIGN_MTT", "synthetic")      # synthetic (uniform, seed = qp) | trained_like (synth.trained_like_msbd_weights, round 5)
+MTT_WEIGHTS = os.environ.get("PMP_CAMPAIGN_MTT", "synthetic")      # synthetic (uniform, seed = qp) | trained_like (trained_like.msbd_weights, round 5)
 
 
 @pytest.fixture(scope="module")
@@ -38,7 +41,7 @@ def test_full_size_parity(eng, comp, qp):
     y, u, v = synth.recipe_r_blocks(N, 5000 + qp + (11 if not luma else 0))
     wq, _ = W.load_net_weights(comp + "_Q", qp)
     if MTT_WEIGHTS == "trained_like":
-        wbd, src = synth.trained_like_msbd_weights(comp, qp), "trained-like (synth.py)"
+        wbd, src = trained_like.msbd_weights(comp, qp), "trained-like (synth.py)"
         eng.load(comp, qp, msbd_weights=wbd)
         print("\n       trained-like MTT weights: activation exponents %s" % eng.activation_report(comp, qp)["exps"], flush=True)
     else:

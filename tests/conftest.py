@@ -7,6 +7,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+if os.path.join(ROOT, "tools") not in sys.path:      # tools/trained_like.py (test-weight data), tools/ref_harness.py
+    sys.path.insert(1, os.path.join(ROOT, "tools"))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 

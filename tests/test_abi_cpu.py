@@ -184,7 +184,7 @@ def test_f16x3_weight_packing_is_exact_to_22_bits(lib, cout, cin, k):
 def test_product_library_has_no_ablation_knobs(lib):
     """The product library ships ONE form of every kernel: the A/B forms that lost their measurement (conv variants 1, 3-9), the
     timing-only builds (wrong results) and the PMP_CONV_VARIANT environment knob exist only in the measurement library
-    libpmp_hip_abl.so (make abl; tools/variants_agree.py, tools/conv_ab.py).  Here the selector accepts the default and nothing else,
+    tools/abl/libpmp_hip_abl.so (make -C tools/abl; tools/variants_agree.py, tools/conv_ab.py).  Here the selector accepts the default and nothing else,
     there is no process-wide variant state, and neither the 32x16-tile kernel nor the Winograd-x kernel is in the code object."""
     assert lib.pmp_debug_set_conv_variant(2) == 0
     for bad in (0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11, 18, 138, 1162, -1, 4096):
@@ -196,12 +196,15 @@ def test_product_library_has_no_ablation_knobs(lib):
         assert sym not in blob, sym                        # ... nor the Winograd-x experiment of round 3, nor its weight packer
     assert b"abl" not in lib.pmp_version()
     # ... and the SOURCES of the product library carry no measurement code either: no conditional compilation on the measurement build, no
-    # timing-only template parameter, no stamp helper - the notebook lives under csrc/abl/ (and tools/experiments/), behind the no-op
-    # hooks of csrc/hooks/ (same header names as csrc/abl/'s, chosen by include path: make vs make abl)
+    # timing-only template parameter, no stamp helper - the notebook lives under tools/abl/ (and tools/experiments/), behind the no-op
+    # hooks of csrc/hooks/ (same header names as tools/abl/'s, chosen by include path: make vs make -C tools/abl); since round 6 nothing of it is inside the product package
     import re
     csrc = os.path.join(os.path.dirname(_lib.LIB_PATH), "csrc")
     product = [f for f in os.listdir(csrc) if f.endswith((".hip", ".cpp", ".h"))] + ["hooks/abl_types.h", "hooks/abl_hooks.h"]
-    assert len(product) >= 20 and os.path.isdir(os.path.join(csrc, "abl"))
+    root = os.path.dirname(os.path.dirname(csrc))
+    assert len(product) >= 20 and not os.path.exists(os.path.join(csrc, "abl")) and os.path.isdir(os.path.join(root, "tools", "abl"))
+    pkg = os.path.dirname(csrc)
+    assert not [f for f in os.listdir(pkg) if "abl" in f], "measurement artefacts inside the product package"
     for f in product:
         src = open(os.path.join(csrc, f)).read()
         assert "PMP_ABLATION" not in src and "g_conv_variant" not in src and "s_memtime" not in src, f

@@ -48,8 +48,8 @@ def test_cli_extension_flags_default_to_reference_behaviour():
     a = D.build_parser().parse_args([])
     assert a.binary is False and a.hostBlocks is False and a.strictBatch is False and a.device is None and a.gpus == 1
     assert a.qps == "22,27,32,37" and a.comps == "Luma,Chroma"
-    assert a.noOverlap is False                                   # round 5: the driver runs the library's overlap mode unless told otherwise
-    assert D.build_parser().parse_args(["--noOverlap"]).noOverlap is True
+    assert a.overlap is False                                     # round 6: opt-in again - the job-level A/B of round 5 showed no gain
+    assert D.build_parser().parse_args(["--overlap"]).overlap is True
     b = D.build_parser().parse_args(["--hostBlocks", "--strictBatch", "--binary", "--batchSize", "7", "--qps", "22", "--comps", "Chroma"])
     assert b.hostBlocks and b.strictBatch and b.binary and b.batchSize == 7 and b.qps == "22" and b.comps == "Chroma"
 

@@ -5,6 +5,9 @@ scale setting.  None of the knobs may change a result (include/pmp.h): this is t
 (the range guard's deferred re-runs, the load-time calibration, the second stream of overlap mode, the context's shared logit buffers)."""
 import numpy as np
 import pytest
+
+import conftest  # noqa: F401 - puts tools/ on sys.path
+import trained_like  # tools/trained_like.py: test-weight data (round 6: out of the product package)
 import torch
 
 from conftest import golden
@@ -17,9 +20,9 @@ def _weights(kind):
     if kind == "benign":
         return synth.synth_msbd_weights("Luma", 22)
     if kind == "trained":
-        return synth.trained_like_msbd_weights("Luma", 22)
+        return trained_like.msbd_weights("Luma", 22)
     if kind == "trained_k":
-        return synth.trained_like_msbd_weights("Luma", 22, trunk_gain=1024.0, gate_gain=64.0)
+        return trained_like.msbd_weights("Luma", 22, trunk_gain=1024.0, gate_gain=64.0)
     w = dict(synth.synth_msbd_weights("Luma", 22))             # "stress": tests/test_gpu_parity.py's range-stress construction
     K = np.float32(2.0 ** 17)
     for k in ("conv_b1_1", "conv_b1_2", "conv_b1_3"):
@@ -118,8 +121,8 @@ def test_random_api_sequences_chroma():
     dev = torch.device("cuda:0")
     y, u, v = synth.recipe_r_blocks(1100, 98)
     d = [torch.from_numpy(a).to(dev) for a in (y, u, v)]
-    kinds = {"benign": lambda: synth.synth_msbd_weights("Chroma", 27), "trained": lambda: synth.trained_like_msbd_weights("Chroma", 27),
-             "trained_k": lambda: synth.trained_like_msbd_weights("Chroma", 27, trunk_gain=4096.0, gate_gain=16.0, att_gain=8.0)}
+    kinds = {"benign": lambda: synth.synth_msbd_weights("Chroma", 27), "trained": lambda: trained_like.msbd_weights("Chroma", 27),
+             "trained_k": lambda: trained_like.msbd_weights("Chroma", 27, trunk_gain=4096.0, gate_gain=16.0, att_gain=8.0)}
     refs = {}
 
     def reference(kind, prec):

@@ -833,8 +833,8 @@ def test_driver_end_to_end_files(eng, oracle_lib, tmp_path):
         assert open(out / "j1" / "PartitionMat" / nm, "rb").read() == open(out2 / "j1" / "PartitionMat" / nm, "rb").read(), nm
 
 
-def test_driver_overlap_default_is_byte_identical(tmp_path):
-    """The CLI driver turns the library's overlap mode ON by default (--noOverlap turns it off): passes of >= 1024 blocks run as two chunks
+def test_driver_overlap_mode_is_byte_identical(tmp_path):
+    """The CLI driver's --overlap turns the library's overlap mode on (opt-in since round 6): passes of >= 1024 blocks run as two chunks
     on two streams.  A sequence large enough to be cut (2 frames of 2048x1088 = 1088 blocks per pass) gives the same files either way."""
     import os
     from pmp_vvc_tip2023_amd import inference_qbd as D, synth
@@ -850,7 +850,7 @@ def test_driver_overlap_default_is_byte_identical(tmp_path):
     with open(cfg / "SeqO.cfg", "w") as f:
         f.write("InputFile                     : SeqO_2048x1088_30.yuv\nInputBitDepth                 : 8\n")
     outs = {}
-    for tag, extra in (("on", []), ("off", ["--noOverlap"])):
+    for tag, extra in (("on", ["--overlap"]), ("off", [])):
         out = tmp_path / ("out_" + tag)
         D.main(["--jobID", "j", "--inputDir", str(inp), "--outDir", str(out), "--seqTable", "table.txt", "--cfgDir", str(cfg), "--ssRatio", "1",
                 "--startSeqID", "0", "--seqNum", "1", "--qps", "22,32", "--allowSyntheticMTT"] + extra)
@@ -1046,7 +1046,11 @@ def test_bench_json_contract(tmp_path):
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert d["parity"]["logit_max_abs_err"] < 1e-3 and d["parity"]["flag_mismatch_vs_oracle_postproc_of_device_logits"] == 0
     assert d["value"] > 50 * cb["value"]   # sanity: the GPU path is not the CPU path
-    assert rf["traffic_source"] is None or "pmc_traffic.json" in rf["traffic_source"]
+    # round 6: `traffic` is printed only when the committed PMC record was taken on THIS build of the kernel file (sha256 stamp), else null + why
+    assert rf["traffic_source"] and (("THIS kernel build" in rf["traffic_source"]) == (rf["traffic"] is not None))
+    fx = d["extra"]["fp32_exact"]               # round 6: the exact-arithmetic datapath (and the cost of a range-guard re-run), witnessed every run
+    assert fx["dtype"] == "f32" and 0 < fx["ctu_per_s"] < d["value"] and fx["roofline"]["peak"] == 157.3
+    assert 0 < fx["roofline"]["frac"] < 1 and abs(fx["roofline"]["frac"] - fx["roofline"]["achieved"] / 157.3) < 1e-3
     hv = rf["hbm_view"]                         # the same launches against the HBM roof: algorithmic bytes / measured launch time
     assert hv["unit"] == "GB/s" and hv["peak"] == 8000 and 0 < hv["frac"] < 1 and abs(hv["frac"] - hv["achieved"] / hv["peak"]) < 1e-3
     assert abs(hv["algorithmic_bytes_per_launch"] - rf["flop_per_launch"] / 73728.0 * 640) < 2

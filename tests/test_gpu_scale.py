@@ -12,6 +12,9 @@ import sys
 
 import numpy as np
 import pytest
+
+import conftest  # noqa: F401 - puts tools/ on sys.path
+import trained_like  # tools/trained_like.py: test-weight data (round 6: out of the product package)
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -53,7 +56,7 @@ def test_full_size_logit_tail_default_datapath_and_guard_fallback(comp, qp, n, m
     y, u, v = synth.recipe_r_blocks(n, 5000 + qp + (0 if luma else 500))
     wq, _ = W.load_net_weights(comp + "_Q", qp)
     if mtt == "trained_like":
-        wbd = synth.trained_like_msbd_weights(comp, qp)
+        wbd = trained_like.msbd_weights(comp, qp)
     else:
         wbd, _ = W.load_net_weights(comp + "_MSBD", qp, allow_synthetic=True)
     oq, obt, od = O.infer_qbd(wq, wbd, O.luma_input(y) if luma else O.chroma_input(y, u, v), luma, batch=64)

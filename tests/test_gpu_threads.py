@@ -15,6 +15,9 @@ import time
 import numpy as np
 import pytest
 
+import conftest  # noqa: F401 - puts tools/ on sys.path
+import trained_like  # tools/trained_like.py: test-weight data (round 6: out of the product package)
+
 pytestmark = pytest.mark.gpu
 
 
@@ -23,7 +26,7 @@ def _inputs():
     from test_gpu_parity import _range_stress_weights
     y, u, v = synth.recipe_r_blocks(1100, 4711)
     qt, bt, dire = synth.random_partition_batch(600, 99, 1, 0.2)
-    return dict(y=y, u=u, v=v, tl=synth.trained_like_msbd_weights("Luma", 22), stress=_range_stress_weights(),
+    return dict(y=y, u=u, v=v, tl=trained_like.msbd_weights("Luma", 22), stress=_range_stress_weights(),
                 benign=synth.synth_msbd_weights("Luma", 22), m2p=(qt, bt, dire))
 
 
@@ -181,7 +184,7 @@ def test_in_process_hook_sequence_from_two_threads(tmp_path):
         for qp in (22, 37):
             src = os.path.join(W.default_weight_dir(), "%s_Q_%d.pmpw" % (comp, qp))
             shutil.copy(src, tmp_path / os.path.basename(src))
-            W.save_pmpw(str(tmp_path / ("%s_BD_%d.pmpw" % (comp, qp))), comp + "_MSBD", qp, synth.trained_like_msbd_weights(comp, qp),
+            W.save_pmpw(str(tmp_path / ("%s_BD_%d.pmpw" % (comp, qp))), comp + "_MSBD", qp, trained_like.msbd_weights(comp, qp),
                         source="trained-like (synth.py)")
     jobs = []
     for bitdepth, width, height, frames, qp in ((8, 1920 // 2, 1080 // 2, 3, 22), (10, 416, 240, 4, 37)):

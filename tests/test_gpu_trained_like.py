@@ -1,4 +1,4 @@
-"""GPU parity on TRAINED-LIKE MTT weights (synth.trained_like_msbd_weights: tensors bootstrapped from the real QT-net tensors, trunk
+"""GPU parity on TRAINED-LIKE MTT weights (trained_like.msbd_weights: tensors bootstrapped from the real QT-net tensors, trunk
 activations at the QT nets' 1e3 range, gated products to 1e4; the reference's *_BD_*.pkl are absent from the mount).
 Goldens: tests/golden/g2b_msbd_trained_like.npz, written by tools/gen_golden.py from the REFERENCE's MTT modules
 (Model_QBD.py:100-155, :198-253) holding exactly these tensors.  Tolerance: north_star's 1e-3 on the logits."""
@@ -6,6 +6,9 @@ import os
 
 import numpy as np
 import pytest
+
+import conftest  # noqa: F401 - puts tools/ on sys.path
+import trained_like  # tools/trained_like.py: test-weight data (round 6: out of the product package)
 import torch
 
 from conftest import golden
@@ -25,7 +28,7 @@ def eng(request):
 
 def _load_tl(e, comp, qp, **gains):
     from pmp_vvc_tip2023_amd import synth
-    w = synth.trained_like_msbd_weights(comp, qp, **gains)
+    w = trained_like.msbd_weights(comp, qp, **gains)
     e.load(comp, qp, msbd_weights=w)                              # the real QT net from weights/, the MTT net replaced
     return w
 
@@ -71,7 +74,7 @@ def _oracle(comp, qp, n):
         y[3] = np.where((np.arange(68)[:, None] // 2 + np.arange(68)[None, :] // 2) % 2, 255, 0)                                   # 2-px checkerboard
         luma = comp == "Luma"
         wq, _ = W.load_net_weights(comp + "_Q", qp)
-        wbd = synth.trained_like_msbd_weights(comp, qp)
+        wbd = trained_like.msbd_weights(comp, qp)
         x = O.luma_input(y) if luma else O.chroma_input(y, u, v)
         _ORACLE[key] = (y, u, v) + tuple(O.infer_qbd(wq, wbd, x, luma, batch=64))
     return _ORACLE[key]
@@ -111,7 +114,7 @@ def test_trained_like_fresh_blocks_vs_oracle(eng, oracle_lib, comp, qp):
     luma = comp == "Luma"
     x = O.luma_input(y) if luma else O.chroma_input(y, u, v)
     with torch.no_grad():
-        o = O.msbd_forward(synth.trained_like_msbd_weights(comp, qp), x, torch.from_numpy(qt), luma)
+        o = O.msbd_forward(trained_like.msbd_weights(comp, qp), x, torch.from_numpy(qt), luma)
     abt = np.stack([t[:, 0].numpy() for t in o], 1); adire = np.stack([t[:, 1].numpy() for t in o], 1)
     e_a, m_a = per_block([(bt, abt), (dire, adire)])
     # (b) end to end, QT net included: the oracle's own q feeds the oracle's MTT net (the trained-like nets pass an error of q on
@@ -173,7 +176,7 @@ def test_activation_scales_report():
             assert r0["exps"] == [0, 0, 0, 0, 0], r0
             assert max(r0["seg_amax"]) < 4096
         for comp, qp in (("Luma", 22), ("Chroma", 27)):
-            e.load(comp, qp, msbd_weights=synth.trained_like_msbd_weights(comp, qp))
+            e.load(comp, qp, msbd_weights=trained_like.msbd_weights(comp, qp))
             base = e.activation_report(comp, qp)
             names = [t[0] for t in base["tensors"]]
             assert len(names) == 49 and names[0] == "stem" and names[1] == "trunk_M1.0.t" and names[-1] == "trunk_B3.2"
@@ -181,7 +184,7 @@ def test_activation_scales_report():
             assert 1e3 < base["seg_amax"][0] < 1e5 and base["exps"][1] == 0 and base["exps"][3] == 0      # gates of O(10..200): no scale needed
             assert all(0 <= x <= 8 for x in base["exps"])
             print("activation scales %s QP%d: exps %s, segment maxima %s" % (comp, qp, base["exps"], ["%.3g" % m for m in base["seg_amax"]]))
-            e.load(comp, qp, msbd_weights=synth.trained_like_msbd_weights(comp, qp, trunk_gain=64.0, gate_gain=16.0))
+            e.load(comp, qp, msbd_weights=trained_like.msbd_weights(comp, qp, trunk_gain=64.0, gate_gain=16.0))
             st = e.activation_report(comp, qp)
             assert np.isclose(st["seg_amax"][0], 64.0 * base["seg_amax"][0], rtol=1e-6)
             assert np.isclose(st["seg_amax"][1], 16.0 * base["seg_amax"][1], rtol=1e-6) or st["seg_amax"][1] >= base["seg_amax"][1]
@@ -204,7 +207,7 @@ def test_attention_trunk_beyond_its_scale_cap_falls_back_to_the_guard():
     g1, g2b = golden("g1_qt.npz"), golden("g2b_msbd_trained_like.npz")
     e = engine.Engine(0, allow_synthetic_mtt=True)
     try:
-        e.load("Luma", 22, msbd_weights=synth.trained_like_msbd_weights("Luma", 22, att_gain=2.0 ** 18))
+        e.load("Luma", 22, msbd_weights=trained_like.msbd_weights("Luma", 22, att_gain=2.0 ** 18))
         rep = e.activation_report("Luma", 22)
         assert rep["exps"][1] == 6 and rep["exps"][3] == 6 and rep["seg_amax"][1] > 65504 * 64
         e.clear_saturation()
@@ -221,7 +224,7 @@ def test_manifest_exponents_skip_the_calibration(tmp_path):
     import shutil
     from pmp_vvc_tip2023_amd import engine, synth, weights as W
     g1 = golden("g1_qt.npz")
-    w = synth.trained_like_msbd_weights("Luma", 22, trunk_gain=64.0)
+    w = trained_like.msbd_weights("Luma", 22, trunk_gain=64.0)
     e1 = engine.Engine(0)
     try:
         e1.load("Luma", 22, msbd_weights=w)
@@ -255,7 +258,7 @@ def test_stale_manifest_exponents_are_ignored_and_a_new_qt_partner_recalibrates(
     import ctypes as C
     import shutil
     from pmp_vvc_tip2023_amd import _lib, engine, synth, weights as W
-    w = synth.trained_like_msbd_weights("Luma", 22, trunk_gain=64.0)
+    w = trained_like.msbd_weights("Luma", 22, trunk_gain=64.0)
     wq22, _ = W.load_net_weights("Luma_Q", 22)
     wq37, _ = W.load_net_weights("Luma_Q", 37)
     e = engine.Engine(0)
@@ -322,14 +325,14 @@ def test_calibrate_pmpw_tool_writes_the_exponents(tmp_path):
     import calibrate_pmpw
     for comp, qp in (("Luma", 22), ("Chroma", 37)):
         shutil.copy(os.path.join(W.default_weight_dir(), "%s_Q_%d.pmpw" % (comp, qp)), tmp_path)
-        W.save_pmpw(str(tmp_path / ("%s_BD_%d.pmpw" % (comp, qp))), comp + "_MSBD", qp, synth.trained_like_msbd_weights(comp, qp), source="test")
+        W.save_pmpw(str(tmp_path / ("%s_BD_%d.pmpw" % (comp, qp))), comp + "_MSBD", qp, trained_like.msbd_weights(comp, qp), source="test")
     done = calibrate_pmpw.calibrate_dir(str(tmp_path), 0, log=lambda *a: None)
     assert len(done) == 2
     e = engine.Engine(0)
     try:
         for comp, qp in (("Luma", 22), ("Chroma", 37)):
             man, tens = W.load_pmpw(str(tmp_path / ("%s_BD_%d.pmpw" % (comp, qp))))
-            ref = synth.trained_like_msbd_weights(comp, qp)
+            ref = trained_like.msbd_weights(comp, qp)
             assert list(tens) == list(ref) and all(np.array_equal(tens[k], ref[k]) for k in ref)
             e.load(comp, qp, msbd_weights=ref)                     # a calibrating load of the same tensors
             assert man["act_exp"] == e.activation_report(comp, qp)["exps"]

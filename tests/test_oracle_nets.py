@@ -3,6 +3,9 @@ reference modules (tools/gen_golden.py).  Tolerance 1e-4 (same arithmetic librar
 the product's tolerance against these same vectors is north_star's 1e-3."""
 import numpy as np
 import pytest
+
+import conftest  # noqa: F401 - puts tools/ on sys.path
+import trained_like  # tools/trained_like.py: test-weight data (round 6: out of the product package)
 import torch
 
 from conftest import golden
@@ -77,19 +80,19 @@ def test_synth_weights_are_deterministic_and_complete():
 @pytest.mark.parametrize("comp", ["Luma", "Chroma"])
 @pytest.mark.parametrize("qp", [22, 27, 32, 37])
 def test_msbd_net_trained_like_weights(comp, qp):
-    """G2b: the reference's MTT modules holding synth.trained_like_msbd_weights (bootstrapped from the real QT tensors; trunks at 1e3).
+    """G2b: the reference's MTT modules holding trained_like.msbd_weights (bootstrapped from the real QT tensors; trunks at 1e3).
     The oracle on the same tensors, the activation maxima that ride along, and the power-of-two stress variants, which must not
     change a single bit of the logits (the heads undo the gains exactly)."""
     g1, g2b = golden("g1_qt.npz"), golden("g2b_msbd_trained_like.npz")
     luma = comp == "Luma"
     x = O.luma_input(g1["block_y"]) if luma else O.chroma_input(g1["block_y"], g1["block_u"], g1["block_v"])
     q = torch.from_numpy(g1["qt_%s_%d" % (comp, qp)])
-    wbd = synth.trained_like_msbd_weights(comp, qp)
+    wbd = trained_like.msbd_weights(comp, qp)
     assert len(wbd) == 72 and all(v.dtype == np.float32 for v in wbd.values())
     taps = {}
     with torch.no_grad():
         o = O.msbd_forward(wbd, x, q, luma, taps=taps)
-        o2 = O.msbd_forward(synth.trained_like_msbd_weights(comp, qp, trunk_gain=64.0, gate_gain=16.0, att_gain=1024.0), x, q, luma)
+        o2 = O.msbd_forward(trained_like.msbd_weights(comp, qp, trunk_gain=64.0, gate_gain=16.0, att_gain=1024.0), x, q, luma)
     for i in range(3):
         assert np.abs(o[i].numpy() - g2b["out%d_%s_%d" % (i, comp, qp)]).max() < TOL
         assert torch.equal(o[i], o2[i])
@@ -98,11 +101,11 @@ def test_msbd_net_trained_like_weights(comp, qp):
     assert np.allclose(got, amax[:5], rtol=1e-3)
     assert 300 < amax[1] < 3000 and 300 < amax[2] < 3000      # the trunks run where the trained QT nets run (SURVEY: 3e3 on 8-bit content)
     with pytest.raises(ValueError):
-        synth.trained_like_msbd_weights(comp, qp, gate_gain=3.0)
+        trained_like.msbd_weights(comp, qp, gate_gain=3.0)
 
 
 def test_trained_like_scale_table_matches_its_generator():
-    """pmp_vvc_tip2023_amd/trained_like_scales.json is the output of tools/calibrate_trained_like.py on synth.trained_like_raw(): a change to
+    """tools/trained_like_scales.json is the output of tools/calibrate_trained_like.py on trained_like.raw(): a change to
     the bootstrap without a regenerated table (or the other way round) must not go unnoticed.  One net re-calibrated here (torch CPU
     convolutions: equal to the committed scalars up to the arithmetic of this host's convolution library)."""
     import json
@@ -112,7 +115,7 @@ def test_trained_like_scale_table_matches_its_generator():
     sys.path.insert(0, os.path.join(root, "tools"))
     import calibrate_trained_like as C
     c, outs = C.calibrate("Chroma", 37)
-    table = json.load(open(os.path.join(root, "pmp_vvc_tip2023_amd", "trained_like_scales.json")))["Chroma"]["37"]
+    table = json.load(open(os.path.join(root, "tools", "trained_like_scales.json")))["Chroma"]["37"]
     assert set(c.scale) == set(table) and len(table) == 72
     for name, want in table.items():
         got = c.scale[name]

@@ -6,7 +6,7 @@
 #include <cstdlib>
 #include <vector>
 
-#include "../pmp_host.h"
+#include "pmp_host.h"
 
 namespace pmp {
 

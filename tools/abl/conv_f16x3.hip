@@ -26,7 +26,7 @@
 #include <type_traits>
 
 #include "abl_kernels.h"
-#include "../split3.h"
+#include "split3.h"
 
 namespace pmp {
 

@@ -36,7 +36,7 @@
 // group for lanes g < 2, tap 8 of the odd group for lanes g >= 2); barrier, burst refill with groups 2, 3, vmcnt(0), barrier;
 // K-steps 9..17.
 #include "abl_kernels.h"
-#include "../split3.h"
+#include "split3.h"
 
 namespace pmp {
 

@@ -21,7 +21,7 @@
 #include <vector>
 
 #include "abl_kernels.h"
-#include "../split3.h"
+#include "split3.h"
 
 namespace pmp {
 

@@ -14,7 +14,7 @@
 //             barrier, epilogue - so one wave of every SIMD is in its K-loop while the other converts and stores.
 // EXACT: pack_h2's K-step list, the products x0*w1, x0*w0, x1*w0 per K-step and accumulator, conv_f16x3.hip's epilogue arithmetic.
 // Timing-only switches (ABL, wrong results): 1 no DMA after the first tile, 2 no MFMAs, 4 no epilogue (stores of zeros stay), 8 no residual.
-#include "../chain16_dev.h"
+#include "chain16_dev.h"
 
 namespace pmp {
 

@@ -12,7 +12,7 @@
 //            Epilogue: 1/S, ReLU, zero outside the image (conv2's padding), two-term split -> the 18x18 intermediate image in LDS (83 KB).
 //   phase 2  conv2 from that image (no staging, no barrier), chain16_dev.h's pass: wave = (cout group, row half).  Epilogue as h2_epilogue:
 //            1/S + identity residual (16-byte loads from global - the tile's input is long gone from LDS), ReLU, split, 16-byte stores.
-#include "../chain16_dev.h"
+#include "chain16_dev.h"
 
 namespace pmp {
 

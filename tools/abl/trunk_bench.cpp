@@ -5,7 +5,7 @@
 #include <cstring>
 #include <vector>
 
-#include "../pmp_host.h"
+#include "pmp_host.h"
 
 namespace pmp {
 struct TrunkPipeArgs {

@@ -1,9 +1,10 @@
 """Timing-only ablations of the direct 5x5 64->64 kernel (conv_f16x3.hip, two-workgroup form) beside the shipped three-workgroup form -
-needs libpmp_hip_abl.so (make abl).  Run on the GPU box."""
+needs libpmp_hip_abl.so (make -C tools/abl).  Run on the GPU box."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import abl_lib  # tools/abl_lib.py: the measurement library lives in tools/abl/
 from pmp_vvc_tip2023_amd import _lib, engine
-_lib.load(_lib.ABL_LIB_PATH)
+_lib.load(abl_lib.ensure())
 eng = engine.Engine(0, allow_synthetic_mtt=True)
 eng.set_precision("f16x3")
 names = {2: "shipped form (three workgroups per CU)", 3: "two workgroups per CU", 11: "no halo requests", 12: "no weight requests", 14: "LDS fragment reads in the first K-step only",

@@ -1,7 +1,7 @@
-"""Per-tensor scales of the trained-like MTT-net weights -> pmp_vvc_tip2023_amd/trained_like_scales.json.
+"""Per-tensor scales of the trained-like MTT-net weights -> tools/trained_like_scales.json.
 
 Build container only (plain torch-CPU convolutions; no reference import needed - tools/gen_golden.py then loads the finished
-tensors into the reference's own modules for the G2b goldens).  Starts from synth.trained_like_raw() - MTT tensors bootstrapped
+tensors into the reference's own modules for the G2b goldens).  Starts from trained_like.raw() - MTT tensors bootstrapped
 from the real QT-net tensors - and walks the forward pass of Model_QBD.py:127-155 / :225-253 ONCE on recipe-R blocks, fixing one
 scalar per conv tensor as it goes (data-dependent initialisation in the LSUV manner), so that
 
@@ -25,12 +25,13 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+import trained_like
 from pmp_vvc_tip2023_amd import synth, weights as W
 
 STEM_MAX = float(os.environ.get('TL_STEM_MAX', 2000.0))
 BETA = float(os.environ.get('TL_BETA', 1.0))
 N_CAL = 48
-OUT = os.path.join(ROOT, "pmp_vvc_tip2023_amd", "trained_like_scales.json")
+OUT = os.path.join(HERE, "trained_like_scales.json")
 
 
 def rms(t):
@@ -47,7 +48,7 @@ class Cal:
     def fix(self, name, factor):
         f = float(np.float32(factor))
         self.scale[name] = f
-        self.w[name] = torch.from_numpy(self.raw[name] * np.float32(f))   # exactly what synth.trained_like_msbd_weights will compute
+        self.w[name] = torch.from_numpy(self.raw[name] * np.float32(f))   # exactly what trained_like.msbd_weights will compute
 
     def rb(self, x, name):
         r = rms(x)
@@ -114,7 +115,7 @@ class Cal:
 
 def calibrate(comp, qp):
     luma = comp == "Luma"
-    raw = synth.trained_like_raw(comp, qp)
+    raw = trained_like.raw(comp, qp)
     y, u, v = synth.recipe_r_blocks(N_CAL, 9000 + qp)
     yt = torch.from_numpy(y).float().unsqueeze(1)
     if luma:

@@ -1,10 +1,11 @@
 """One conv layer, fp32-MFMA kernel vs a split kernel (bf16x6, or f16x3 with `h2` as first argument), random data (run on the GPU box).
-The ablate* / stamps modes need libpmp_hip_abl.so (make -C pmp_vvc_tip2023_amd/csrc abl); the product library has no timing-only kernels."""
+The ablate* / stamps modes need libpmp_hip_abl.so (make -C tools/abl); the product library has no timing-only kernels."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import abl_lib  # tools/abl_lib.py: the measurement library lives in tools/abl/
 from pmp_vvc_tip2023_amd import _lib, engine
-# the timing-only (wrong-result) kernel builds live in the measurement library only: make -C pmp_vvc_tip2023_amd/csrc abl
-_lib.load(_lib.ABL_LIB_PATH if any(a in ("ablate", "ablate5", "ablate_h2", "stamps") for a in sys.argv[1:3]) else None)
+# the timing-only (wrong-result) kernel builds live in the measurement library only: make -C tools/abl
+_lib.load(abl_lib.ensure() if any(a in ("ablate", "ablate5", "ablate_h2", "stamps") for a in sys.argv[1:3]) else None)
 eng = engine.Engine(0, allow_synthetic_mtt=True)
 split = "bf16x6"
 if len(sys.argv) > 1 and sys.argv[1] == "h2":

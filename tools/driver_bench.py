@@ -100,11 +100,11 @@ for N in (2, 4, 8):
         crit = st.t["gpu_wait"] / N + (dt - st.t["gpu_wait"])
     print("  projected critical path at %d ranks: %.3f s  (x%.2f)%s" % (N, crit, dt / crit, "  [weight loading is the longer leg]" if emit_mode == "sharded" and hidden > rows / N else ""))
 
-# --abOverlap 1: the driver's default (overlap mode on) against --noOverlap, alternating, same process and box (round 5)
+# --abOverlap 1: --overlap against the driver's default (off since round 6), alternating, same process and box
 if opt.get("--abOverlap") == "1":
     res = {"on": [], "off": []}
     for rep in range(4):
-        for tag, extra in (("on", []), ("off", ["--noOverlap"])):
+        for tag, extra in (("on", ["--overlap"]), ("off", [])):
             t1 = time.time()
             D.main(args + extra)
             res[tag].append(time.time() - t1)

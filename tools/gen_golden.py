@@ -4,7 +4,7 @@ Run in the build container only (needs /root/reference):   python tools/gen_gold
 Every output is produced by calling the reference's own functions:
   G1  Model_QBD.{Luma,Chroma}_Q_Net          real weights, 4 QPs           -> g1_qt.npz
   G2  Model_QBD.{Luma,Chroma}_MSBD_Net       synthetic weights (synth.py)  -> g2_msbd.npz
-  G2b Model_QBD.{Luma,Chroma}_MSBD_Net       TRAINED-LIKE weights (synth.trained_like_msbd_weights: bootstrapped from the real QT
+  G2b Model_QBD.{Luma,Chroma}_MSBD_Net       TRAINED-LIKE weights (trained_like.msbd_weights: bootstrapped from the real QT
                                              tensors, trunks at 1e3, gated products to 9e3), 4 QPs -> g2b_msbd_trained_like.npz
   G3  Map2Partition.map_to_parititon         random/adversarial maps       -> g3_m2p.npz
   G3b Metrics.eli_structual_error + Map2Partition.map_to_parititon on the value RANGE the nets can hand over: |bt|, |dire| up to
@@ -30,6 +30,7 @@ import numpy as np
 import torch
 
 import ref_harness as R
+import trained_like
 from pmp_vvc_tip2023_amd import synth
 from oracle import nets_torch as O
 from oracle import postproc as P
@@ -100,19 +101,19 @@ def gen_g2b():
     (ii) that the power-of-two stress variants (trunk_gain, gate_gain) leave the reference's logits bit-identical."""
     g1 = dict(np.load(os.path.join(OUT, "g1_qt.npz")))
     y, u, v = g1["block_y"], g1["block_u"], g1["block_v"]
-    out = {"meta": np.array(META + "; MSBD weights = synth.trained_like_msbd_weights(comp, qp); inputs = g1 blocks, q = g1 logits")}
+    out = {"meta": np.array(META + "; MSBD weights = trained_like.msbd_weights(comp, qp); inputs = g1 blocks, q = g1 logits")}
     for comp in ("Luma", "Chroma"):
         luma = comp == "Luma"
         x = O.luma_input(y) if luma else O.chroma_input(y, u, v)
         for qp in (22, 27, 32, 37):
             q = torch.from_numpy(g1["qt_%s_%d" % (comp, qp)])
-            wbd = synth.trained_like_msbd_weights(comp, qp)
+            wbd = trained_like.msbd_weights(comp, qp)
             net = R.ref_net(comp + "_MSBD", wbd)
             taps = {}
             with torch.no_grad():
                 o = net(x, q)
                 o_or = O.msbd_forward(wbd, x, q, luma, taps=taps)
-                net2 = R.ref_net(comp + "_MSBD", synth.trained_like_msbd_weights(comp, qp, trunk_gain=64.0, gate_gain=16.0))
+                net2 = R.ref_net(comp + "_MSBD", trained_like.msbd_weights(comp, qp, trunk_gain=64.0, gate_gain=16.0))
                 o2 = net2(x, q)
             for a, b in zip(o, o_or):
                 assert (a - b).abs().max().item() < 1e-4, "oracle MSBD restatement drifted (trained-like weights)"

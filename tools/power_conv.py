@@ -4,8 +4,9 @@ import ctypes as C, json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 if len(sys.argv) > 1 and sys.argv[1] == "child":
+    import abl_lib  # tools/abl_lib.py: the measurement library lives in tools/abl/
     from pmp_vvc_tip2023_amd import _lib, engine
-    _lib.load(_lib.ABL_LIB_PATH)          # the Winograd-x form lives in the measurement library
+    _lib.load(abl_lib.ensure())          # the Winograd-x form lives in the measurement library
     k, wino = int(sys.argv[2]), int(sys.argv[3])
     eng = engine.Engine(0, allow_synthetic_mtt=True)
     eng.set_precision("f16x3")

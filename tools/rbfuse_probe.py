@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Fused ResidualBlock(64, 64, 3) prototype (csrc/abl/rbfuse_proto.hip, measurement library) against the product's launch pair on the
+"""Fused ResidualBlock(64, 64, 3) prototype (tools/abl/rbfuse_proto.hip, measurement library) against the product's launch pair on the
 same random tensors: bit comparison, then interleaved timing, then the prototype's timing-only builds.
-    make -C pmp_vvc_tip2023_amd/csrc abl && python tools/rbfuse_probe.py [blocks] [size]"""
+    make -C tools/abl && python tools/rbfuse_probe.py [blocks] [size]"""
 import ctypes as C
 import os
 import sys
@@ -9,13 +9,14 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: F401  (loads the HIP runtime first)
+import abl_lib  # tools/abl_lib.py: the measurement library lives in tools/abl/
 from pmp_vvc_tip2023_amd import _lib
 
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     size = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-    lib = _lib.open_library(os.path.join(ROOT, "pmp_vvc_tip2023_amd", "libpmp_hip_abl.so"))
+    lib = _lib.open_library(abl_lib.ensure())
     ctx = C.c_void_p()
     assert lib.pmp_create(0, C.byref(ctx)) == 0
     f = lib.pmp_abl_rbfuse_bench

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Layer-pipelined persistent trunk kernel (csrc/abl/conv_f16x3.hip: trunk_pipe_kernel, measurement library) against one launch per layer:
+"""Layer-pipelined persistent trunk kernel (tools/abl/conv_f16x3.hip: trunk_pipe_kernel, measurement library) against one launch per layer:
 bit comparison of every layer's output, interleaved timing.
-    make -C pmp_vvc_tip2023_amd/csrc abl && python tools/trunk_probe.py [blocks] [size] [layers] [delay,delay,...] [grid]"""
+    make -C tools/abl && python tools/trunk_probe.py [blocks] [size] [layers] [delay,delay,...] [grid]"""
 import ctypes as C
 import os
 import sys
@@ -9,6 +9,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: F401  (loads the HIP runtime first)
+import abl_lib  # tools/abl_lib.py: the measurement library lives in tools/abl/
 from pmp_vvc_tip2023_amd import _lib
 
 
@@ -19,7 +20,7 @@ def main():
     delays = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else [6]
     grid = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     iters = int(os.environ.get("TRUNK_ITERS", "3"))
-    lib = _lib.open_library(os.path.join(ROOT, "pmp_vvc_tip2023_amd", "libpmp_hip_abl.so"))
+    lib = _lib.open_library(abl_lib.ensure())
     ctx = C.c_void_p()
     assert lib.pmp_create(0, C.byref(ctx)) == 0
     f = lib.pmp_abl_trunk_bench

@@ -1,11 +1,11 @@
-"""The A/B forms of the f16x3 Cout = 64 convolution (measurement library libpmp_hip_abl.so, `make -C pmp_vvc_tip2023_amd/csrc abl`)
+"""The A/B forms of the f16x3 Cout = 64 convolution (measurement library libpmp_hip_abl.so, `make -C tools/abl`)
 against the shipped form: logits of the whole luma net bit for bit (same K order, same accumulators), and the 3x3 Cout = 64
 kernel forms on shapes the nets never launch against the exact fp32 kernel.  Run on the GPU box:
 
     python tools/variants_agree.py
 
 A regression check of the notebook, not a parity test: the product library ships none of these forms.  Since round 4
-the notebook forms of the three convolution kernel files are separate sources (csrc/abl/), so the first check is that the measurement
+the notebook forms of the three convolution kernel files are separate sources (tools/abl/), so the first check is that the measurement
 library's DEFAULT form still computes what the product library computes, bit for bit, on every datapath."""
 import ctypes as C
 import os
@@ -14,6 +14,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
+import abl_lib  # tools/abl_lib.py: the measurement library lives in tools/abl/
 from pmp_vvc_tip2023_amd import _lib, engine
 
 g1 = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "g1_qt.npz"))
@@ -30,7 +31,7 @@ for prec in ("f16x3", "bf16x6", "fp32"):
         product[(prec, comp)] = eng.inference_pre_QBD(comp, 22, y, u, v)
 eng.close()
 _lib._lib = None                                     # both builds in one process (ctypes loads them RTLD_LOCAL): forget the first handle
-_lib.load(_lib.ABL_LIB_PATH)
+_lib.load(abl_lib.ensure())
 eng = engine.Engine(0, allow_synthetic_mtt=True)
 assert b"abl" in eng.lib.pmp_version()
 for prec in ("f16x3", "bf16x6", "fp32"):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Weight-stationary persistent 3x3 64->64 convolution (csrc/abl/conv_ws.hip, measurement library) against the product's launch on the same
+"""Weight-stationary persistent 3x3 64->64 convolution (tools/abl/conv_ws.hip, measurement library) against the product's launch on the same
 random tensors: bit comparison, interleaved timing, the prototype's timing-only builds.
-    make -C pmp_vvc_tip2023_amd/csrc abl && python tools/ws_probe.py [blocks] [size] [once]"""
+    make -C tools/abl && python tools/ws_probe.py [blocks] [size] [once]"""
 import ctypes as C
 import os
 import sys
@@ -9,6 +9,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: F401  (loads the HIP runtime first)
+import abl_lib  # tools/abl_lib.py: the measurement library lives in tools/abl/
 from pmp_vvc_tip2023_amd import _lib
 
 
@@ -16,7 +17,7 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     size = int(sys.argv[2]) if len(sys.argv) > 2 else 64
     once = len(sys.argv) > 3 and sys.argv[3] == "once"       # under rocprofv3: the exact build only
-    lib = _lib.open_library(os.path.join(ROOT, "pmp_vvc_tip2023_amd", "libpmp_hip_abl.so"))
+    lib = _lib.open_library(abl_lib.ensure())
     ctx = C.c_void_p()
     assert lib.pmp_create(0, C.byref(ctx)) == 0
     f = lib.pmp_abl_ws_bench

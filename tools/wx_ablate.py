@@ -1,8 +1,9 @@
-"""Timing-only ablations of the Winograd-x kernel (conv_f16x3_wx.hip) - needs libpmp_hip_abl.so (make abl).  Run on the GPU box."""
+"""Timing-only ablations of the Winograd-x kernel (conv_f16x3_wx.hip) - needs libpmp_hip_abl.so (make -C tools/abl).  Run on the GPU box."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import abl_lib  # tools/abl_lib.py: the measurement library lives in tools/abl/
 from pmp_vvc_tip2023_amd import _lib, engine
-_lib.load(_lib.ABL_LIB_PATH)
+_lib.load(abl_lib.ensure())
 eng = engine.Engine(0, allow_synthetic_mtt=True)
 eng.set_precision("f16x3")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024

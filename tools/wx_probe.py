@@ -1,13 +1,14 @@
-"""Winograd-x form of the 3x3 64->64 convolutions (conv_f16x3_wx.hip, measurement library: make abl) against the direct form: one layer
+"""Winograd-x form of the 3x3 64->64 convolutions (conv_f16x3_wx.hip, measurement library: make -C tools/abl) against the direct form: one layer
 on random data (error vs the exact fp32 kernel, time), the whole nets against the oracle WITH the parity assertions a product kernel
 has to pass (logits within 1e-3, split flags bit-exact on the device logits, range guard repairs a saturating net through it), and the
 full luma / chroma step.  Run on the GPU box; exits non-zero if a check fails."""
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+import abl_lib  # tools/abl_lib.py: the measurement library lives in tools/abl/
 from pmp_vvc_tip2023_amd import _lib, engine, synth, weights as W
 from oracle import nets_torch as O, postproc as P
-_lib.load(_lib.ABL_LIB_PATH)
+_lib.load(abl_lib.ensure())
 
 eng = engine.Engine(0, allow_synthetic_mtt=True)
 eng.set_precision("f16x3")
