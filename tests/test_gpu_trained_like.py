@@ -340,3 +340,29 @@ def test_calibrate_pmpw_tool_writes_the_exponents(tmp_path):
             assert man["act_fp"] == ["%016x" % W.fingerprint(ref), "%016x" % W.fingerprint(wq)]
     finally:
         e.close()
+
+
+def test_acceptance_tool_end_to_end(tmp_path):
+    """tools/accept_bd_weights.py, the whole flow: reference-format pickles named as the trained MTT files will be
+    -> .pmpw -> calibrated manifests (exponents + fingerprints) -> fresh blocks on all three datapaths against the oracle -> JSON verdict."""
+    import sys
+    import torch as _t
+    from pmp_vvc_tip2023_amd import weights as W
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import accept_bd_weights as A
+    src = tmp_path / "CTU_Models"
+    src.mkdir()
+    for comp, qp in (("Luma", 22), ("Chroma", 37)):
+        for net, tens in ((comp + "_Q", W.load_net_weights(comp + "_Q", qp)[0]), (comp + "_BD", trained_like.msbd_weights(comp, qp))):
+            _t.save({"module." + k: _t.from_numpy(v.copy()) for k, v in tens.items()}, str(src / ("%s_%d.pkl" % (net, qp))),
+                    _use_new_zipfile_serialization=False)
+    v = A.accept(str(src), blocks=48, log=lambda *a: None)
+    assert v["ok"] and v["on_default_datapath"], v
+    assert set(v["pairs"]) == {"Luma QP22", "Chroma QP37"} and set(v["calibrate"]) == {"Luma_BD_22.pmpw", "Chroma_BD_37.pmpw"}
+    p = v["pairs"]["Luma QP22"]
+    assert p["manifest_act_exp"] == p["calibration"]["exps"] == p["datapaths"]["f16x3"]["activation_exps"] and len(p["manifest_act_fp"]) == 2
+    assert len(p["calibration"]["tensor_amax"]) == 49 and max(p["calibration"]["segment_amax"]) > 1e3      # trained scale, recorded per tensor
+    for prec in ("f16x3", "bf16x6", "fp32"):
+        d = p["datapaths"][prec]
+        assert d["within_tolerance"] and d["flags_bit_exact_on_device_logits"] and d["saturation_reruns"] == 0 and d["blocks_over_tolerance"] == 0

@@ -61,6 +61,41 @@ def test_model_dir_with_bd_pickles_is_a_complete_model_dir(tmp_path):
     assert W.find_net_weights("Luma_Q", 22, d)[0] == "pmpw" and W.find_net_weights("Luma_MSBD", 22, d)[0] == "pkl"
 
 
+def test_acceptance_tool_converts_and_checks_a_bd_model_dir(tmp_path):
+    """tools/accept_bd_weights.py, the part that needs no GPU (--convert-only): a directory as a user of the reference would have it -
+    reference-format pickles named <Comp>_{Q,BD}_<qp>.pkl, here the real QT tensors and the trained-like MTT tensors - becomes a
+    directory of .pmpw files with the same bits, its (QT, MTT) pairs are found, and a file with a missing tensor, a wrong shape or a
+    NaN is named in the verdict instead of reaching the library."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import accept_bd_weights as A
+    import trained_like
+    src = tmp_path / "CTU_Models"
+    src.mkdir()
+    tl = {}
+    for comp, qp in (("Luma", 22), ("Chroma", 37)):
+        wq, _ = W.load_net_weights(comp + "_Q", qp)
+        tl[comp] = trained_like.msbd_weights(comp, qp)
+        _write_ref_pkl(str(src / ("%s_Q_%d.pkl" % (comp, qp))), wq, False, True)
+        _write_ref_pkl(str(src / ("%s_BD_%d.pkl" % (comp, qp))), tl[comp], True, True)
+    (src / "notes.pkl").write_bytes(b"not a model file")                      # skipped by name
+    v = A.accept(str(src), blocks=8, log=lambda *a: None, convert_only=True)
+    assert v["ok"] and v["convert"]["pairs"] == ["Luma QP22", "Chroma QP37"] and v["convert"]["problems"] == []
+    man, got = W.load_pmpw(str(src / "pmpw" / "Chroma_BD_37.pmpw"))
+    assert man["net"] == "Chroma_MSBD" and man["qp"] == 37 and all(np.array_equal(got[k], tl["Chroma"][k]) for k in tl["Chroma"])
+    # broken inputs
+    bad = dict(tl["Luma"]); del bad["trunk_M2.3.left.2.weight"]
+    bad["conv_B2.weight"] = bad["conv_B2.weight"][:, :4]
+    bad["conv_b1_1.bias"] = np.full_like(bad["conv_b1_1.bias"], np.nan)
+    _write_ref_pkl(str(src / "Luma_BD_22.pkl"), bad, False, True)
+    os.remove(src / "Chroma_Q_37.pkl"); os.remove(src / "pmpw" / "Chroma_Q_37.pmpw")
+    v = A.accept(str(src), blocks=8, log=lambda *a: None, convert_only=True)
+    assert not v["ok"]
+    pr = {os.path.basename(p.get("file", p.get("pair", ""))): p for p in v["convert"]["problems"]}
+    assert pr["Luma_BD_22.pmpw"]["missing"] == ["trunk_M2.3.left.2.weight"] and pr["Luma_BD_22.pmpw"]["wrong_shape"] == ["conv_B2.weight"]
+    assert pr["Luma_BD_22.pmpw"]["non_finite"] == ["conv_b1_1.bias"] and "only Chroma_MSBD" in pr["Chroma QP37"]["error"]
+
+
 @pytest.mark.skipif(not os.path.isdir(REF_MODELS), reason="the reference checkout is only present in the build container")
 @pytest.mark.parametrize("comp", ["Luma", "Chroma"])
 @pytest.mark.parametrize("qp", [22, 27, 32, 37])
