@@ -89,8 +89,8 @@ _QT_KNOWN = {("bf16x6", "Luma", 22): (), ("fp32", "Luma", 22): ()}
 @pytest.mark.parametrize("comp,qp", [("Luma", 22), ("Luma", 37), ("Chroma", 27), ("Chroma", 37)])
 def test_trained_like_fresh_blocks_vs_oracle(eng, oracle_lib, comp, qp):
     """320 fresh blocks (flat, saturated, white-noise and checkerboard blocks included) against the torch oracle holding the same
-    tensors: north_star's ABSOLUTE 1e-3 on every block whose logits are inside Map2Partition's operating range (|logit| <= 8), and at
-    most 2 % of the natural blocks may lie outside it; the record of what the guard did rides along.  Then the DEVICE logits of all 320
+    tensors: north_star's ABSOLUTE 1e-3 on every natural block and on every block whose logits are inside Map2Partition's operating range
+    (|logit| <= 8) - only the synthetic extremes beyond it get a relative tolerance; the record of what the guard did rides along.  Then the DEVICE logits of all 320
     blocks - the checkerboard's +-300 and the noise block's +-75 among them - through pmp_postprocess against the oracle's
     post-processing of the same numbers (the kernel's +-100 saturation of the rounded depth sees real net output)."""
     y, u, v, oq, obt, odire = _oracle(comp, qp, 320)
@@ -123,16 +123,21 @@ def test_trained_like_fresh_blocks_vs_oracle(eng, oracle_lib, comp, qp):
     inside = np.maximum(m_a, m_b) <= 8.0
     natural = np.arange(len(y)) >= 4
     n_out = int((natural & ~inside).sum())
-    worst = int(np.argmax(np.where(inside, e_b, 0)))
-    print("trained-like %s QP%d %s: |logit| <= 8 on %d of %d natural blocks; inside: MTT alone max %.2e, end to end max %.2e (block %d); "
-          "outside (relative to |logit|/8): max %.2e; reruns %d" % (comp, qp, eng.get_precision(), int((natural & inside).sum()), int(natural.sum()),
-          e_a[inside].max(), e_b[worst], worst, (e_b / np.maximum(1.0, m_b / 8.0))[~inside].max() if (~inside).any() else 0.0, eng.saturation_reruns()))
-    assert (e_a[inside] < TOL).all(), "%s QP%d MTT net on identical inputs: block %d off by %g" % (comp, qp, int(np.argmax(np.where(inside, e_a, 0))), e_a[inside].max())
-    assert (e_b[inside] < TOL).all(), "%s QP%d end to end: block %d off by %g (|logit| %g)" % (comp, qp, worst, e_b[worst], m_b[worst])
-    assert n_out <= 0.02 * natural.sum(), "%d of %d natural blocks leave the operating range: the absolute tolerance covers too little" % (n_out, int(natural.sum()))
-    # beyond the operating range - the synthetic extremes (2-px checkerboard: +-300, white noise: +-75; the torch oracle itself is 6.6e-4 from
-    # an fp64 evaluation on the checkerboard block) and the few natural blocks counted above - the same tolerance RELATIVE to |logit| / 8
-    assert (e_a[~inside] < TOL * np.maximum(1.0, m_a[~inside] / 8.0)).all() and (e_b[~inside] < TOL * np.maximum(1.0, m_b[~inside] / 8.0)).all()
+    # north_star's ABSOLUTE 1e-3: on every block whose logits are inside Map2Partition's operating range (|logit| <= 8) AND on every natural
+    # (recipe-R) block whatever its logits - a few per cent of them reach |logit| 10..50 on these nets (Luma QP22: 2.8 %), none needs slack
+    absolute = inside | natural
+    worst = int(np.argmax(np.where(absolute, e_b, 0)))
+    print("trained-like %s QP%d %s: %d of %d natural blocks beyond |logit| 8 (max |logit| %.1f); absolute tolerance on %d blocks: MTT alone max %.2e, "
+          "end to end max %.2e (block %d, |logit| %.1f); synthetic extremes (relative to |logit|/8): max %.2e; reruns %d"
+          % (comp, qp, eng.get_precision(), n_out, int(natural.sum()), float(m_b[natural].max()), int(absolute.sum()), e_a[absolute].max(), e_b[worst], worst,
+             m_b[worst], (e_b / np.maximum(1.0, m_b / 8.0))[~absolute].max() if (~absolute).any() else 0.0, eng.saturation_reruns()))
+    assert (e_a[absolute] < TOL).all(), "%s QP%d MTT net on identical inputs: block %d off by %g" % (comp, qp, int(np.argmax(np.where(absolute, e_a, 0))), e_a[absolute].max())
+    assert (e_b[absolute] < TOL).all(), "%s QP%d end to end: block %d off by %g (|logit| %g)" % (comp, qp, worst, e_b[worst], m_b[worst])
+    assert n_out <= 0.05 * natural.sum(), "%d of %d natural blocks leave the operating range: these are no longer trained-LIKE nets" % (n_out, int(natural.sum()))
+    # only the synthetic extremes beyond the operating range (2-px checkerboard: +-300, white noise: +-75; the torch oracle itself is 6.6e-4
+    # from an fp64 evaluation on the checkerboard block) get the same tolerance RELATIVE to |logit| / 8
+    assert (~absolute).sum() <= 4
+    assert (e_a[~absolute] < TOL * np.maximum(1.0, m_a[~absolute] / 8.0)).all() and (e_b[~absolute] < TOL * np.maximum(1.0, m_b[~absolute] / 8.0)).all()
     assert max(m_b[:4].max(), m_a[:4].max()) > 50 or not luma    # the extremes ARE extreme (luma): the post-processing below sees them
     assert eng.saturation_reruns() == 0
     # the split flags of the fused call = the reference's post-processing of ITS device logits, the +-300 blocks included

@@ -126,11 +126,11 @@ def verify_pair(eng, out, comp, qp, blocks, log):
                      np.array_equal(q8, np.nan_to_num(dq, nan=0.0).astype(np.uint8)))
         e2e = int(((hor != o_flags[0]).any(axis=(1, 2)) | (ver != o_flags[1]).any(axis=(1, 2)) | (d8 != o_flags[3]).any(axis=(1, 2, 3)) |
                    (q8 != np.nan_to_num(o_flags[2], nan=0.0).astype(np.uint8)).any(axis=(1, 2))).sum())
-        # north_star's ABSOLUTE 1e-3 wherever the logits are inside Map2Partition's operating range (|logit| <= 8: depths 0..6, directions
-        # +-1); beyond it - the synthetic extremes, a net that emits +-300 on a checkerboard - the same tolerance relative to |logit| / 8
-        # (float32 itself: the torch oracle is 6.6e-4 from an fp64 evaluation there), and the number of such blocks is reported
+        # north_star's ABSOLUTE 1e-3 on every natural (recipe-R) block; the four synthetic extremes get it relative to |logit| / 8 beyond
+        # Map2Partition's operating range (|logit| <= 8: a net that emits +-300 on a checkerboard - float32 itself: the torch oracle is
+        # 6.6e-4 from an fp64 evaluation there); how many natural blocks leave the operating range is reported
         mag = np.maximum(np.abs(oq).reshape(blocks, -1).max(1), np.maximum(np.abs(obt).reshape(blocks, -1).max(1), np.abs(od).reshape(blocks, -1).max(1)))
-        tol_b = TOL * np.maximum(1.0, mag / 8.0)
+        tol_b = TOL * np.where(np.arange(blocks) < 4, np.maximum(1.0, mag / 8.0), 1.0)     # relative only for the four synthetic extremes
         over = per_block >= tol_b
         worst = int(np.argmax(per_block / tol_b))
         r = {"max_abs_err": {"qt": float(np.abs(qt - oq).max()), "bt": float(np.abs(bt - obt).max()), "dire": float(np.abs(dire - od).max())},
