@@ -692,7 +692,7 @@ def test_fused_path_on_overflowing_nets_matches_the_oracle_on_its_own_logits(eng
             hor, ver, q8, d8, qt, bt, dire = e2.infer_postprocess("Luma", 22, y, want_logits=True)
             if case == "head_biases_nonfinite":
                 assert np.isposinf(bt[:, 0]).all() and np.isnan(dire[:, 0]).all() and np.isposinf(bt[:, 1]).all()
-                assert not np.isfinite(bt[:, 2]).any() and np.isposinf(dire[:, 2]).all()
+                assert not np.isfinite(bt[:, 2]).any() and not np.isfinite(dire[:, 2]).any()      # -inf / +inf, or NaN where the trunk fed NaN into the head
             with np.errstate(invalid="ignore"):
                 oh, ov, oq, od = oracle_lib.seq_post_process(qt, bt, dire, "Luma", 1, 64 * len(y), 64, None)
                 assert np.array_equal(q8, np.nan_to_num(oq, nan=0.0).astype(np.uint8))
