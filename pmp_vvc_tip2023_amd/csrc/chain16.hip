@@ -1,137 +1,86 @@
-// chain16.hip — the 16x16-resolution tails of the four nets as ONE workgroup per block with every activation resident in LDS
-// (f16x3 datapath).  At 16x16 a block IS a tile: a 64-channel tensor is 65 KB, so the chains below - until round 3 about thirty launches per
-// pass that existed only to move <= 65 KB per block through HBM between tiny layers - need no halo recompute and no HBM round trip:
+// chain16.hip — the 16x16-resolution tails of the four nets with every activation of a ResidualBlock resident in LDS (f16x3 datapath),
+// TWO blocks per CU (round 6; building blocks and the memory plan: tail16_dev.h).  At 16x16 a block IS a tile, so the chains below - until
+// round 3 about thirty launches per pass that existed only to move <= 65 KB per block through HBM between tiny layers - need no halo
+// recompute, and only the two 64-channel tensors that do not fit beside their consumers make a round trip through L2:
 //
-//   MTT nets (Model_QBD.py:116-124, :138-146 / :214-223, :236-244), msbd_branch16_kernel:
-//       x5 -> trunk_B1 (RB 64->32, 32->16, 16->8) -> conv_B1 -> out0
-//          -> cat[up2(q), out0] -> trunk_Att1 (RB 3->32, 32->64) * x5 -> trunk_B2 -> conv_B2 -> out1, out1[:,0] += out0[:,0]
-//   QT nets (Model_QBD.py:71-76, :83-91 / :169-174, :181-189), qt_tail16_kernel:
-//       x4 -> resblock_q3 -> cat[x5, up2(mp2), up4(mp4), up8(mp8)] -> resblock_q4 -> resblock_q5, max_pool2d(2) -> resblock_q6 -> conv_q2
+//   MTT nets (Model_QBD.py:116-124, :138-146 / :214-223, :236-244):
+//       branch16_kernel   x5 -> trunk_B1 (RB 64->32, 32->16, 16->8) -> conv_B1 -> out0
+//       att16_kernel      cat[up2(q), out0] -> trunk_Att1 (RB 3->32, 32->64) * x5 -> xb1 (global, 64 KB per block)
+//       branch16_kernel   xb1 -> trunk_B2 -> conv_B2 -> out1, out1[:,0] += out0[:,0]
+//   QT nets (Model_QBD.py:71-76, :83-91 / :169-174, :181-189):
+//       q3_rb64_kernel    x4 -> resblock_q3 -> x5 (global, fp32, 32 KB per block: the multi-scale pool reads fp32)
+//       qt_rest16_kernel  cat[x5, up2(mp2), up4(mp4), up8(mp8)] -> resblock_q4 -> resblock_q5, max_pool2d(2) -> resblock_q6 -> conv_q2
+//
+// Round 4's form did each net's tail in ONE kernel (msbd_branch16_kernel, qt_tail16_kernel: 143 KB of LDS, 168-230 VGPRs, eight waves: one
+// workgroup per CU, matrix pipes 0.46 / 0.32 busy behind 24 dependent passes).  Here a workgroup is four waves with <= 80 KB of LDS, two
+// per CU: one block's barriers, epilogues and heads run beside the other's MFMAs.
 //
 // BIT-IDENTICAL to the launch-per-layer path (nets.cpp with fusion off; tests/test_gpu_parity.py): the convolutions consume the same
 // packed weight streams (pack_h2, pack.cpp) in the same K-step order with the same three products per K-step (x0*w1, x0*w0, x1*w0) into
 // the same fp32 accumulators, the epilogues apply the same operations in the same order (1/S, residual or 1x1 shortcut pass, ReLU, gate,
 // 2x2 pool, two-term fp16 split with the range clamp), tensors that the launch path hands to its fp32 kernels stay fp32 here too, and the
-// fp32 kernels (heads, 8x8 direct convolutions, multi-scale pool) are restated with their accumulation order.  What changes is where
-// the tensors live.
-//
-// LDS: six "slots" of one 16-channel group each in the halo-image form the MFMA kernels stage ([plane][18 x 18 px][16 ch] fp16, zero
-// border: 20 736 B), i.e. a 64-channel input next to its 32-channel intermediate, plus an fp32 area; 143-147 KB: one workgroup of eight
-// waves per CU.  A wave owns four or eight image rows x one 16-channel group of a layer's output (C16Tile); every layer ends "registers -> barrier -> LDS" so that an
-// output may overwrite the slots of a tensor that was still being read.
-#include "chain16_dev.h"
+// fp32 kernels (heads, 8x8 direct convolutions, multi-scale pool) are restated with their accumulation order.
+#include "tail16_dev.h"
 
 namespace pmp {
 
-
-// ===================================================================================================== MTT nets: B1, Att1, B2
-struct MsbdBranch16Args {
-    const unsigned short *x5; size_t x5_stride;     // [N][4][16][16][16] split-2: trunk_M2's pooled output (and attention 1's gate operand)
-    const float *qt;                                // raw QT logits [N][64]
-    float *bt, *dire;                               // [N][3][256]: layers 0 and 1 are written here
-    C16RB b1[3], att[2], b2[3];
-    const float *head_w[2], *head_b[2];
+// ===================================================================================================== RB(64 -> 32) -> fp32 (resblock_q3)
+struct Q3Args {
+    const unsigned short *x4; size_t x4_stride;     // [N][4][16][16][16] split-2: resblock_q2's pooled output
+    float *x5;                                      // [N][2][256][16] fp32
+    T16RB q3;
     unsigned *sat;
-    float att_scale;
 };
 
-__global__ __launch_bounds__(512, 2) void msbd_branch16_kernel(MsbdBranch16Args a)
+__global__ __launch_bounds__(T16_THREADS, 2) void q3_rb64_kernel(Q3Args a)
 {
-    __shared__ __attribute__((aligned(16))) char slots[C16_NSLOT * C16_SLOT];
-    __shared__ __attribute__((aligned(16))) float f0[256 * 16];
-    __shared__ float s_bt[256], s_dire[256];
-    const int n = blockIdx.x, tid = threadIdx.x;
-    const unsigned short *x5 = a.x5 + (size_t)n * 4 * 4096;
-    char *S0 = slots, *S2 = slots + 2 * C16_SLOT, *S4 = slots + 4 * C16_SLOT;
-    float amax = 0.f;
-    C16Pass<9, 2, 4> pb0;            // first pass of a branch trunk: started in front of whatever precedes it
-    c16_wstart(pb0, a.b1[0].w0);
-    c16_clear_slots(slots);
+    __shared__ __attribute__((aligned(16))) char slots[T16_NSLOT * T16_SLOT];
+    typedef T16Tile<2> WT;
+    const int n = blockIdx.x;
+    const unsigned short *x = a.x4 + (size_t)n * 4 * 4096;
+    T16Pass<9, 2> p1;
+    t16_wstart(p1, a.q3.w0, 2, WT::ct());
+    T16Fetch f01;
+    t16_fetch(f01, x, a.x4_stride, 0);
+    t16_clear(slots, T16_NSLOT * T16_SLOT);
     __syncthreads();
-    c16_load_image(S0, x5, a.x5_stride, 4);
-    __syncthreads();
-
-    auto branch = [&](const C16RB r0, const C16RB r1, const C16RB r2, const float *hw, const float *hb, int layer) __attribute__((always_inline)) {
-        // trunk_B: 64 ch in S0..3 -> 32 ch (S0..1) -> 16 ch (S2) -> 8 ch fp32 (f0) -> head
-        C16Pass<9, 1, 2> pb1;
-        C16Pass<9, 1, 1> pb2;
-        amax = c16_rb<2, 4, true, false, C16_IMG>(r0, S0, S4, C16Epi{0.f, nullptr, nullptr, 0, S0, nullptr}, amax, pb0, [&]() __attribute__((always_inline)) { c16_wstart(pb1, r1.w0); });
-        amax = c16_rb<1, 2, true, false, C16_IMG>(r1, S0, S4, C16Epi{0.f, nullptr, nullptr, 0, S2, nullptr}, amax, pb1, [&]() __attribute__((always_inline)) { c16_wstart(pb2, r2.w0); });
-        amax = c16_rb<1, 1, true, false, C16_F32>(r2, S2, S4, C16Epi{0.f, nullptr, nullptr, 0, nullptr, f0}, amax, pb2, []() {});
-        if (tid < 256) {
-            float acc0, acc1;
-            c16_head<16>(f0, hw, hb, 2, tid, acc0, acc1);
-            if (layer > 0) acc0 += s_bt[tid];          // out1[:, 0] += out0[:, 0]  (Model_QBD.py:146)
-            const size_t o = ((size_t)n * 3 + layer) * 256 + tid;
-            a.bt[o] = acc0;
-            a.dire[o] = acc1;
-            s_bt[tid] = acc0;
-            s_dire[tid] = acc1;
-        }
-        __syncthreads();
-    };
-    branch(a.b1[0], a.b1[1], a.b1[2], a.head_w[0], a.head_b[0], 0);
-
-    // attention input cat[up2(q), out0] (conv_misc.hip: att_input_kernel, S = 16) -> S0, channels 3..15 zero
-    if (tid < 256) {
-        const int x = tid & 15, y = tid >> 4;
-        f32x4 v = {a.qt[(size_t)n * 64 + (y >> 1) * 8 + (x >> 1)], s_bt[tid], s_dire[tid], 0.f};
-        v *= a.att_scale;      // the attention segment's activation scale (a power of two: exact)
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        amax = c16_store_split(S0, 0, tid, 0, v, amax);
-        c16_store_split(S0, 0, tid, 4, z, 0.f);
-        c16_store_split(S0, 0, tid, 8, z, 0.f);
-        c16_store_split(S0, 0, tid, 12, z, 0.f);
-    }
-    __syncthreads();
-    // trunk_Att1: 3 -> 32 (S4..5), 32 -> 64 gated by x5 (S0..3)
-    C16Pass<9, 2, 1> pa0;
-    C16Pass<9, 4, 2> pa1;
-    c16_wstart(pa0, a.att[0].w0);
-    amax = c16_rb<2, 1, true, false, C16_IMG>(a.att[0], S0, S4, C16Epi{0.f, nullptr, nullptr, 0, S4, nullptr}, amax, pa0, [&]() __attribute__((always_inline)) { c16_wstart(pa1, a.att[1].w0); });
-    amax = c16_rb<4, 2, true, true, C16_IMG>(a.att[1], S4, S0, C16Epi{0.f, nullptr, x5, a.x5_stride, S0, nullptr}, amax, pa1, [&]() __attribute__((always_inline)) { c16_wstart(pb0, a.b2[0].w0); });
-    branch(a.b2[0], a.b2[1], a.b2[2], a.head_w[1], a.head_b[1], 1);
-    sat_report(a.sat, amax);
+    f32x4 acc[8];
+    const float amax = t16_rb64(a.q3, x, a.x4_stride, slots, f01, acc, 0.f, p1, []() {});
+    t16_epilogue<8, false, false, T16_F32>(acc, WT::row0(), T16Epi{a.q3.s2, nullptr, nullptr, 0, nullptr, a.x5 + ((size_t)n * 2 + WT::ct()) * 4096, nullptr, 0}, 0.f);
+    sat_report(a.sat, amax);                        // the block's intermediate is split; its fp32 output is not clamped
 }
 
-// ===================================================================================================== QT nets: q3 .. conv_q2
-struct QtTail16Args {
-    const unsigned short *x4; size_t x4_stride;     // [N][4][16][16][16] split-2: resblock_q2's pooled output
+// ===================================================================================================== QT nets: x6 .. conv_q2
+struct QtRest16Args {
+    const float *x5;                                // [N][2][256][16] fp32: resblock_q3's output
     float *qt;                                      // [N][64]
-    C16RB q3, q4, q5;
+    T16RB q4, q5;
     const float *d_w0, *d_w2, *d_wsc;               // resblock_q6 on the 8x8 map: plain fp32 [tap][cin][8], [tap][8][8], [32][8] (conv_direct8_kernel)
     const float *head_w, *head_b;
     unsigned *sat;
 };
 
-__global__ __launch_bounds__(512, 2) void qt_tail16_kernel(QtTail16Args a)
+__global__ __launch_bounds__(T16_THREADS, 2) void qt_rest16_kernel(QtRest16Args a)
 {
-    __shared__ __attribute__((aligned(16))) char lds[C16_NSLOT * C16_SLOT + 8192];
-    const int n = blockIdx.x, tid = threadIdx.x;
-    char *S0 = lds, *S2 = lds + 2 * C16_SLOT, *S4 = lds + 4 * C16_SLOT;
-    float *F = reinterpret_cast<float *>(S4);       // fp32 area = slots 4, 5 and the 8 KB behind them (no halo image lives there after q3)
-    float *x5 = F;                                  // [2][256][16]
-    float *p2 = F + 8192, *p4 = p2 + 2 * 1024, *p8 = p4 + 2 * 256;     // [2][64][16], [2][16][16], [2][4][16]
+    __shared__ __attribute__((aligned(16))) char slots[T16_NSLOT * T16_SLOT];
+    typedef T16Tile<2> WT;
+    const int n = blockIdx.x, tid = threadIdx.x, ct = WT::ct(), row0 = WT::row0();
+    char *A = slots, *C = slots + 2 * T16_SLOT;
+    const float *x5 = a.x5 + (size_t)n * 2 * 4096;
+    float *p2 = reinterpret_cast<float *>(C), *p4 = p2 + 2 * 1024, *p8 = p4 + 2 * 256;     // [2][64][16], [2][16][16], [2][4][16]: 10.5 KB of slot C
     float amax = 0.f;
-    C16Pass<9, 2, 4> pq3;
-    c16_wstart(pq3, a.q3.w0);
-    c16_clear_slots(lds);
-    __syncthreads();
-    c16_load_image(S0, a.x4 + (size_t)n * 4 * 4096, a.x4_stride, 4);
-    __syncthreads();
-    // resblock_q3: 64 -> 32, output fp32 (the multi-scale pool reads it).  Its intermediate uses S4..5, which then becomes the fp32 area.
-    amax = c16_rb<2, 4, true, false, C16_F32>(a.q3, S0, S4, C16Epi{0.f, nullptr, nullptr, 0, nullptr, x5}, amax, pq3, []() {});
+    t16_clear(slots, 2 * T16_SLOT);                 // the window's borders; C, D become images only as resblock_q5's intermediate (cleared then)
     // multi-scale pool (conv_misc.hip: multipool_concat_kernel), both groups
-    for (int i = tid; i < 2 * 1024; i += 512) {
+    for (int i = tid; i < 2 * 1024; i += T16_THREADS) {
         const int cb = i >> 10, j = i & 1023, c = j & 15, x = (j >> 4) & 7, y = j >> 7;
         const float *q = x5 + cb * 4096 + ((2 * y) * 16 + 2 * x) * 16 + c;
         p2[i] = fmaxf(fmaxf(q[0], q[16]), fmaxf(q[256], q[272]));
     }
     __syncthreads();
-    {
-        const int cb = tid >> 8, j = tid & 255, c = j & 15, x = (j >> 4) & 3, y = j >> 6;
+    for (int i = tid; i < 512; i += T16_THREADS) {
+        const int cb = i >> 8, j = i & 255, c = j & 15, x = (j >> 4) & 3, y = j >> 6;
         const float *q = p2 + cb * 1024 + ((2 * y) * 8 + 2 * x) * 16 + c;
-        p4[tid] = fmaxf(fmaxf(q[0], q[16]), fmaxf(q[128], q[144]));
+        p4[i] = fmaxf(fmaxf(q[0], q[16]), fmaxf(q[128], q[144]));
     }
     __syncthreads();
     if (tid < 128) {
@@ -141,59 +90,64 @@ __global__ __launch_bounds__(512, 2) void qt_tail16_kernel(QtTail16Args a)
     }
     __syncthreads();
     // x6 = cat[x5, up2(mp2), up4(mp4), up8(mp8)], 128 channels: never materialised as a whole - channel-group pair p (= source p) is
-    // written to S0..1 when the convolution needs it
+    // written to the window A, B when the convolution needs it
     auto x6_pair = [&](int p) __attribute__((always_inline)) {
-        for (int i = tid; i < 2048; i += 512) {        // (group, pixel, quad of channels)
+        for (int i = tid; i < 2048; i += T16_THREADS) {        // (group, pixel, quad of channels)
             const int c4 = (i & 3) * 4, px = (i >> 2) & 255, cb = i >> 10, x = px & 15, y = px >> 4;
             const float *s = p == 0 ? x5 + cb * 4096 + px * 16
                            : p == 1 ? p2 + cb * 1024 + ((y >> 1) * 8 + (x >> 1)) * 16
                            : p == 2 ? p4 + cb * 256 + ((y >> 2) * 4 + (x >> 2)) * 16
                                     : p8 + cb * 64 + ((y >> 3) * 2 + (x >> 3)) * 16;
-            amax = c16_store_split(S0, cb, px, c4, *reinterpret_cast<const f32x4 *>(s + c4), amax);
+            amax = t16_store_split(A + cb * T16_SLOT, px, c4, *reinterpret_cast<const f32x4 *>(s + c4), amax);
         }
     };
-    f32x4 acc[C16Tile<2>::RW];
-    // resblock_q4: 128 -> 32.  First conv: 8 groups = 4 pairs of 9 K-steps; second conv: 32 -> 32 from S2..3, then the 1x1 shortcut over x6
-    c16_zero<2>(acc);
+    f32x4 acc[8];
+    // resblock_q4: 128 -> 32.  First conv: 8 groups = 4 pairs of 9 K-steps; second conv: 32 -> 32, then the 1x1 shortcut over x6 again
+    t16_zero<8>(acc);
     for (int p = 0; p < 4; ++p) {
-        C16Pass<9, 2, 2> pp;
-        c16_wstart(pp, a.q4.w0 + (size_t)p * 9 * (2 * 2 * 64 * 8));
+        T16Pass<9, 2> pp;
+        t16_wstart(pp, a.q4.w0 + (size_t)p * 9 * 2 * T16_KSTEP, 2, ct);
         x6_pair(p);
         __syncthreads();
-        c16_accumulate<9, 2, 2>(S0, a.q4.w0 + (size_t)p * 9 * (2 * 2 * 64 * 8), acc, pp);
+        t16_accumulate<9, 2, 8>(A, row0, acc, pp);
         __syncthreads();
     }
-    C16Pass<9, 2, 2> pq4;
-    c16_wstart(pq4, a.q4.w2);
-    amax = c16_epilogue<2, false, false, C16_IMG>(acc, C16Epi{a.q4.s0, nullptr, nullptr, 0, S2, nullptr}, amax);
+    T16Pass<9, 2> pq4;
+    t16_wstart(pq4, a.q4.w2, 2, ct);
+    amax = t16_epilogue<8, false, false, T16_IMG>(acc, row0, T16Epi{a.q4.s0, nullptr, nullptr, 0, A + ct * T16_SLOT, nullptr, nullptr, 0}, amax);   // the window is free: the intermediate takes it
     __syncthreads();
-    c16_zero<2>(acc);
-    c16_accumulate<9, 2, 2>(S2, a.q4.w2, acc, pq4);
+    t16_zero<8>(acc);
+    t16_accumulate<9, 2, 8>(A, row0, acc, pq4);
+    __syncthreads();
     for (int p = 0; p < 4; ++p) {
-        C16Pass<1, 2, 2> pp;
-        c16_wstart(pp, a.q4.wsc + (size_t)p * (2 * 2 * 64 * 8));
+        T16Pass<1, 2> pp;
+        t16_wstart(pp, a.q4.wsc + (size_t)p * 2 * T16_KSTEP, 2, ct);
         x6_pair(p);
         __syncthreads();
-        c16_accumulate<1, 2, 2>(S0, a.q4.wsc + (size_t)p * (2 * 2 * 64 * 8), acc, pp);
+        t16_accumulate<1, 2, 8>(A, row0, acc, pp);
         __syncthreads();
     }
-    C16Pass<9, 2, 2> pq5;
-    c16_wstart(pq5, a.q5.w0);
-    amax = c16_epilogue<2, false, false, C16_IMG>(acc, C16Epi{a.q4.s2, nullptr, nullptr, 0, S0, nullptr}, amax);   // x7 -> S0..1 (every wave is past the last barrier)
+    T16Pass<9, 2> pq5;
+    t16_wstart(pq5, a.q5.w0, 2, ct);
+    t16_clear(C, 2 * T16_SLOT);                     // the pools are dead: C, D become resblock_q5's intermediate (zero borders)
+    amax = t16_epilogue<8, false, false, T16_IMG>(acc, row0, T16Epi{a.q4.s2, nullptr, nullptr, 0, A + ct * T16_SLOT, nullptr, nullptr, 0}, amax);   // x7 -> A, B
     __syncthreads();
-    // resblock_q5: 32 -> 32, identity shortcut, max_pool2d(2) -> fp32 [2][64][16] over the dead x5
-    float *x8 = F;
-    amax = c16_rb<2, 2, false, false, C16_POOL>(a.q5, S0, S2, C16Epi{0.f, nullptr, nullptr, 0, nullptr, x8}, amax, pq5, []() {});
+    // resblock_q5: 32 -> 32, identity shortcut, max_pool2d(2) -> fp32 [2][64][16]
+    amax = t16_rb<2, 2, false>(a.q5, A, C, acc, amax, pq5, []() {});
+    float *x8 = reinterpret_cast<float *>(C);       // over the dead intermediate
+    t16_epilogue<8, true, false, T16_POOL>(acc, row0, T16Epi{a.q5.s2, A + ct * T16_SLOT, nullptr, 0, nullptr, x8 + ct * 1024, nullptr, 0}, 0.f);
+    __syncthreads();
     // resblock_q6 on the 8x8 map (conv_misc.hip: conv_direct8_kernel - fp32 FMA chains: taps row-major, channels ascending, shortcut last);
-    // one (pixel, cout) chain per thread
-    float *t8 = F + 2048, *y8 = t8 + 1024;          // [64][16] each, channels 8..15 zero
-    float *wd0 = F + 4096, *wd2 = wd0 + 9 * 32 * 8, *wds = wd2 + 9 * 8 * 8;     // the block's three weight tensors: 12.5 KB
-    for (int i = tid; i < 9 * 32 * 8; i += 512) wd0[i] = a.d_w0[i];
-    for (int i = tid; i < 9 * 8 * 8; i += 512) wd2[i] = a.d_w2[i];
-    if (tid < 32 * 8) wds[tid] = a.d_wsc[tid];
+    // one (pixel, cout) chain per thread and half
+    float *F = reinterpret_cast<float *>(A);        // A, B are dead: 39 KB
+    float *t8 = F, *y8 = t8 + 1024;                 // [64][16] each, channels 8..15 zero
+    float *wd0 = y8 + 1024, *wd2 = wd0 + 9 * 32 * 8, *wds = wd2 + 9 * 8 * 8;     // the block's three weight tensors: 12.5 KB
+    for (int i = tid; i < 9 * 32 * 8; i += T16_THREADS) wd0[i] = a.d_w0[i];
+    for (int i = tid; i < 9 * 8 * 8; i += T16_THREADS) wd2[i] = a.d_w2[i];
+    wds[tid] = a.d_wsc[tid];
     __syncthreads();
-    {
-        const int co = tid & 7, px = tid >> 3, x = px & 7, y = px >> 3;
+    for (int t = tid; t < 512; t += T16_THREADS) {
+        const int co = t & 7, px = t >> 3, x = px & 7, y = px >> 3;
         float v = 0.f;
         for (int dy = 0; dy < 3; ++dy) {
             const int yy = y + dy - 1;
@@ -209,8 +163,11 @@ __global__ __launch_bounds__(512, 2) void qt_tail16_kernel(QtTail16Args a)
         }
         t8[px * 16 + co] = fmaxf(v, 0.f);
         t8[px * 16 + 8 + co] = 0.f;
-        __syncthreads();
-        v = 0.f;
+    }
+    __syncthreads();
+    for (int t = tid; t < 512; t += T16_THREADS) {
+        const int co = t & 7, px = t >> 3, x = px & 7, y = px >> 3;
+        float v = 0.f;
         for (int dy = 0; dy < 3; ++dy) {
             const int yy = y + dy - 1;
             if (yy < 0 || yy >= 8) continue;
@@ -225,44 +182,166 @@ __global__ __launch_bounds__(512, 2) void qt_tail16_kernel(QtTail16Args a)
 #pragma unroll
         for (int ci = 0; ci < 32; ++ci) v = fmaf(x8[(ci >> 4) * 1024 + px * 16 + (ci & 15)], wds[ci * 8 + co], v);
         y8[px * 16 + co] = fmaxf(v, 0.f);
-        __syncthreads();
     }
+    __syncthreads();
     if (tid < 64) {
         float acc0, acc1;
-        c16_head<8>(y8, a.head_w, a.head_b, 1, tid, acc0, acc1);
+        t16_head<8>(y8, a.head_w, a.head_b, 1, tid, acc0, acc1);
         a.qt[(size_t)n * 64 + tid] = acc0;
     }
     sat_report(a.sat, amax);
 }
 
+// ===================================================================================================== MTT nets: trunk_B + head
+struct Branch16Args {
+    const unsigned short *x; size_t x_stride;       // [N][4][16][16][16] split-2: x5 (layer 0) or x5 * att0 (layer 1)
+    float *bt, *dire;                               // [N][3][256]: plane `layer` is written; layer 1 adds plane 0 of bt (Model_QBD.py:146)
+    T16RB r[3];
+    const float *head_w, *head_b;
+    unsigned *sat;
+    int layer;
+};
+
+__global__ __launch_bounds__(T16_THREADS, 2) void branch16_kernel(Branch16Args a)
+{
+    __shared__ __attribute__((aligned(16))) char slots[T16_NSLOT * T16_SLOT];
+    typedef T16Tile<2> WT;
+    const int n = blockIdx.x, tid = threadIdx.x;
+    char *A = slots, *C = slots + 2 * T16_SLOT, *D = slots + 3 * T16_SLOT;
+    const unsigned short *x = a.x + (size_t)n * 4 * 4096;
+    float amax = 0.f;
+    T16Pass<9, 2> pb0;
+    t16_wstart(pb0, a.r[0].w0, 2, WT::ct());
+    T16Fetch f01;
+    t16_fetch(f01, x, a.x_stride, 0);
+    t16_clear(slots, T16_NSLOT * T16_SLOT);
+    __syncthreads();
+    // trunk_B.0: 64 ch (global, through the window) -> 32 ch (A, B)
+    T16Pass<9, 2> pb1;
+    {
+        f32x4 acc[8];
+        amax = t16_rb64(a.r[0], x, a.x_stride, slots, f01, acc, amax, pb0, [&]() __attribute__((always_inline)) { t16_wstart(pb1, a.r[1].w0, 1, 0); });
+        amax = t16_epilogue<8, false, false, T16_IMG>(acc, WT::row0(), T16Epi{a.r[0].s2, nullptr, nullptr, 0, A + WT::ct() * T16_SLOT, nullptr, nullptr, 0}, amax);
+        __syncthreads();
+    }
+    // trunk_B.1: 32 -> 16 (D), trunk_B.2: 16 -> 8 as fp32 over A, then the head
+    const int row1 = T16Tile<1>::row0();
+    float *f0 = reinterpret_cast<float *>(A);
+    T16Pass<9, 1> pb2;
+    f32x4 acc[4];
+    amax = t16_rb<1, 2, true>(a.r[1], A, C, acc, amax, pb1, [&]() __attribute__((always_inline)) { t16_wstart(pb2, a.r[2].w0, 1, 0); });
+    amax = t16_epilogue<4, false, false, T16_IMG>(acc, row1, T16Epi{a.r[1].s2, nullptr, nullptr, 0, D, nullptr, nullptr, 0}, amax);
+    __syncthreads();
+    amax = t16_rb<1, 1, true>(a.r[2], D, C, acc, amax, pb2, []() {});
+    t16_epilogue<4, false, false, T16_F32>(acc, row1, T16Epi{a.r[2].s2, nullptr, nullptr, 0, nullptr, f0, nullptr, 0}, 0.f);
+    __syncthreads();
+    {
+        float acc0, acc1;
+        t16_head<16>(f0, a.head_w, a.head_b, 2, tid, acc0, acc1);
+        const size_t o = ((size_t)n * 3 + a.layer) * 256 + tid;
+        if (a.layer > 0) acc0 += a.bt[o - 256];     // out1[:, 0] += out0[:, 0]  (Model_QBD.py:146)
+        a.bt[o] = acc0;
+        a.dire[o] = acc1;
+    }
+    sat_report(a.sat, amax);
+}
+
+// ===================================================================================================== MTT nets: attention 1
+struct Att16Args {
+    const float *qt, *bt, *dire;                    // raw QT logits [N][64]; out0 = plane 0 of [N][3][256]
+    const unsigned short *x5; size_t x5_stride;     // the gate operand [N][4][16][16][16] split-2
+    unsigned short *xb; size_t xb_stride;           // out: x5 * att0, same layout
+    T16RB att[2];
+    unsigned *sat;
+    float att_scale;
+};
+
+__global__ __launch_bounds__(T16_THREADS, 2) void att16_kernel(Att16Args a)
+{
+    __shared__ __attribute__((aligned(16))) char slots[T16_NSLOT * T16_SLOT];
+    typedef T16Tile<2> W2;
+    const int n = blockIdx.x, tid = threadIdx.x, wv = tid >> 6;
+    char *A = slots, *B = slots + T16_SLOT, *C = slots + 2 * T16_SLOT;
+    float amax = 0.f;
+    T16Pass<9, 1> pa0;
+    t16_wstart(pa0, a.att[0].w0, 2, W2::ct());
+    t16_clear(slots, T16_NSLOT * T16_SLOT);
+    __syncthreads();
+    // attention input cat[up2(q), out0] (conv_misc.hip: att_input_kernel, S = 16) -> B, channels 3..15 stay zero
+    {
+        const int x = tid & 15, y = tid >> 4;
+        f32x4 v = {a.qt[(size_t)n * 64 + (y >> 1) * 8 + (x >> 1)], a.bt[(size_t)n * 768 + tid], a.dire[(size_t)n * 768 + tid], 0.f};
+        v *= a.att_scale;      // the attention segment's activation scale (a power of two: exact)
+        amax = t16_store_split(B, tid, 0, v, amax);
+    }
+    __syncthreads();
+    // trunk_Att1.0: 3 -> 32, intermediate in C, D, output over A, B
+    T16Pass<9, 2> pm;
+    {
+        f32x4 acc[8];
+        amax = t16_rb<2, 1, true>(a.att[0], B, C, acc, amax, pa0, [&]() __attribute__((always_inline)) { t16_wstart(pm, a.att[1].w0, 4, W2::ct()); });
+        amax = t16_epilogue<8, false, false, T16_IMG>(acc, W2::row0(), T16Epi{a.att[0].s2, nullptr, nullptr, 0, A + W2::ct() * T16_SLOT, nullptr, nullptr, 0}, amax);
+        __syncthreads();
+    }
+    // trunk_Att1.1: 32 (A, B) -> 64, gated by x5.  Its 64-channel intermediate is produced and consumed pair by pair through C, D: the second
+    // convolution's K-steps 0..8 read groups 0 and 1 only, 9..17 groups 2 and 3; every wave owns one output group x all 16 rows.
+    f32x4 acc2[16];
+    t16_zero<16>(acc2);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        f32x4 accm[8];
+        t16_zero<8>(accm);
+        t16_accumulate<9, 2, 8>(A, W2::row0(), accm, pm);
+        T16Pass<9, 2> p2;
+        t16_wstart(p2, a.att[1].w2 + (size_t)h * 9 * 4 * T16_KSTEP, 4, wv);
+        amax = t16_epilogue<8, false, false, T16_IMG>(accm, W2::row0(), T16Epi{a.att[1].s0, nullptr, nullptr, 0, C + W2::ct() * T16_SLOT, nullptr, nullptr, 0}, amax);
+        __syncthreads();
+        t16_accumulate<9, 2, 16>(C, 0, acc2, p2);
+        if (h == 0) t16_wstart(pm, a.att[1].w0, 4, 2 + W2::ct());
+        __syncthreads();                               // before the next pair (or nobody: the slots are not written again)
+    }
+    {
+        T16Pass<1, 2> p3;
+        t16_wstart(p3, a.att[1].wsc, 4, wv);
+        t16_accumulate<1, 2, 16>(A, 0, acc2, p3);
+    }
+    const size_t go = ((size_t)n * 4 + wv) * 4096;
+    amax = t16_epilogue<16, false, true, T16_GLB>(acc2, 0, T16Epi{a.att[1].s2, nullptr, a.x5 + go, a.x5_stride, nullptr, nullptr, a.xb + go, a.xb_stride}, amax);
+    sat_report(a.sat, amax);
+}
+
 // ===================================================================================================== host side
+static T16RB rbw(const Chain16RB &r) { return T16RB{r.w0, r.w2, r.wsc, r.s0, r.s2}; }
+
 hipError_t launch_msbd_branch16(hipStream_t s, const Chain16MsbdArgs &h)
 {
-    if (h.N <= 0) return hipErrorInvalidValue;
-    MsbdBranch16Args a{};
-    a.x5 = h.x5; a.x5_stride = h.x5_stride; a.qt = h.qt; a.bt = h.bt; a.dire = h.dire; a.sat = h.sat; a.att_scale = h.att_scale;
-    for (int i = 0; i < 3; ++i) {
-        a.b1[i] = C16RB{h.b1[i].w0, h.b1[i].w2, h.b1[i].wsc, h.b1[i].s0, h.b1[i].s2};
-        a.b2[i] = C16RB{h.b2[i].w0, h.b2[i].w2, h.b2[i].wsc, h.b2[i].s0, h.b2[i].s2};
-    }
-    for (int i = 0; i < 2; ++i) {
-        a.att[i] = C16RB{h.att[i].w0, h.att[i].w2, h.att[i].wsc, h.att[i].s0, h.att[i].s2};
-        a.head_w[i] = h.head_w[i]; a.head_b[i] = h.head_b[i];
-    }
-    hipLaunchKernelGGL(msbd_branch16_kernel, dim3(h.N), dim3(512), 0, s, a);
+    if (h.N <= 0 || !h.xb) return hipErrorInvalidValue;
+    Branch16Args b{};
+    b.x = h.x5; b.x_stride = h.x5_stride; b.bt = h.bt; b.dire = h.dire; b.sat = h.sat; b.layer = 0;
+    for (int i = 0; i < 3; ++i) b.r[i] = rbw(h.b1[i]);
+    b.head_w = h.head_w[0]; b.head_b = h.head_b[0];
+    hipLaunchKernelGGL(branch16_kernel, dim3(h.N), dim3(T16_THREADS), 0, s, b);
+    Att16Args a{};
+    a.qt = h.qt; a.bt = h.bt; a.dire = h.dire; a.x5 = h.x5; a.x5_stride = h.x5_stride; a.xb = h.xb; a.xb_stride = h.xb_stride;
+    a.att[0] = rbw(h.att[0]); a.att[1] = rbw(h.att[1]); a.sat = h.sat; a.att_scale = h.att_scale;
+    hipLaunchKernelGGL(att16_kernel, dim3(h.N), dim3(T16_THREADS), 0, s, a);
+    b.x = h.xb; b.x_stride = h.xb_stride; b.layer = 1;
+    for (int i = 0; i < 3; ++i) b.r[i] = rbw(h.b2[i]);
+    b.head_w = h.head_w[1]; b.head_b = h.head_b[1];
+    hipLaunchKernelGGL(branch16_kernel, dim3(h.N), dim3(T16_THREADS), 0, s, b);
     return hipGetLastError();
 }
 
 hipError_t launch_qt_tail16(hipStream_t s, const Chain16QtArgs &h)
 {
-    if (h.N <= 0) return hipErrorInvalidValue;
-    QtTail16Args a{};
-    a.x4 = h.x4; a.x4_stride = h.x4_stride; a.qt = h.qt; a.sat = h.sat;
-    a.q3 = C16RB{h.q3.w0, h.q3.w2, h.q3.wsc, h.q3.s0, h.q3.s2};
-    a.q4 = C16RB{h.q4.w0, h.q4.w2, h.q4.wsc, h.q4.s0, h.q4.s2};
-    a.q5 = C16RB{h.q5.w0, h.q5.w2, h.q5.wsc, h.q5.s0, h.q5.s2};
+    if (h.N <= 0 || !h.x5) return hipErrorInvalidValue;
+    Q3Args q{h.x4, h.x4_stride, h.x5, rbw(h.q3), h.sat};
+    hipLaunchKernelGGL(q3_rb64_kernel, dim3(h.N), dim3(T16_THREADS), 0, s, q);
+    QtRest16Args a{};
+    a.x5 = h.x5; a.qt = h.qt; a.sat = h.sat;
+    a.q4 = rbw(h.q4); a.q5 = rbw(h.q5);
     a.d_w0 = h.d_w0; a.d_w2 = h.d_w2; a.d_wsc = h.d_wsc; a.head_w = h.head_w; a.head_b = h.head_b;
-    hipLaunchKernelGGL(qt_tail16_kernel, dim3(h.N), dim3(512), 0, s, a);
+    hipLaunchKernelGGL(qt_rest16_kernel, dim3(h.N), dim3(T16_THREADS), 0, s, a);
     return hipGetLastError();
 }
 

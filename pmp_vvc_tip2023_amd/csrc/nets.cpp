@@ -288,12 +288,14 @@ int forward_q(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, con
         if (q6 == w.rb.end() || !q6->second.direct) return set_err(c, PMP_E_INVALID, "graph: no weights for resblock_q6");
         if (!g.c16rb("resblock_q3", a.q3, flops, 256) || !g.c16rb("resblock_q4", a.q4, flops, 256) || !g.c16rb("resblock_q5", a.q5, flops, 256)) return g.rc;
         flops += 2.0 * n * 64 * 8 * (32 * 9 + 8 * 9 + 32) + 2.0 * n * 64 * 72.0;
-        a.x4 = x4.s(); a.x4_stride = x4.stride; a.qt = qt; a.N = n; a.sat = g.sat();
+        Act x5 = g.alloc(32, 16, 16, false);        // resblock_q3's fp32 output: from q3_rb64_kernel to qt_rest16_kernel through L2
+        a.x4 = x4.s(); a.x4_stride = x4.stride; a.x5 = x5.p; a.qt = qt; a.N = n; a.sat = g.sat();
         a.d_w0 = q6->second.w0; a.d_w2 = q6->second.w2; a.d_wsc = q6->second.wsc; a.head_w = w.head_w[0]; a.head_b = w.head_b[0];
         if (g.live()) {
             KScope ks(c, K_CONV_OTHER, flops);
             g.check(launch_qt_tail16(c->stream, a), "qt_tail16");
         }
+        g.release(x5);
         g.release(x4);
         return g.rc;
     }
@@ -333,7 +335,8 @@ int forward_msbd(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, 
             ok = g.c16rb("trunk_B1." + std::to_string(i), a.b1[i], flops, 256) && g.c16rb("trunk_B2." + std::to_string(i), a.b2[i], flops, 256);
         for (int i = 0; i < 2 && ok; ++i) ok = g.c16rb("trunk_Att1." + std::to_string(i), a.att[i], flops, 256);
         if (!ok) return g.rc;
-        a.x5 = x5.s(); a.x5_stride = x5.stride; a.qt = qt; a.bt = bt; a.dire = dire; a.N = n; a.sat = g.sat();
+        Act xb = g.alloc(64, 16, 16, true);         // x5 * att0: from att16_kernel to trunk_B2's branch16_kernel through L2
+        a.x5 = x5.s(); a.x5_stride = x5.stride; a.xb = xb.s(); a.xb_stride = xb.stride; a.qt = qt; a.bt = bt; a.dire = dire; a.N = n; a.sat = g.sat();
         a.att[1].s2 = std::ldexp(a.att[1].s2, g.E(1) + g.E(0) - g.E(2));     // the gate product x5 * att0: from segments 1 and 0 into segment 2
         a.att_scale = std::ldexp(1.f, -g.E(1));
         for (int i = 0; i < 2; ++i) { a.head_w[i] = g.head_weights(i, i); a.head_b[i] = w.head_b[i]; }
@@ -341,6 +344,7 @@ int forward_msbd(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, 
             KScope ks(c, K_CONV_OTHER, flops);
             g.check(launch_msbd_branch16(c->stream, a), "msbd_branch16");
         }
+        g.release(xb);
         g.release(x5);
     } else {
         // branch B1 -> out0 (x5 stays: attention 1 gates it, :143)

@@ -57,12 +57,13 @@ hipError_t launch_split2_to_f32(hipStream_t s, const unsigned short *x, float *o
 
 // ------------------------------------------------------------------------------------------------ 16x16 tails, one workgroup per block
 // chain16.hip (f16x3 datapath): the layers of a net that run at 16x16 resolution - where a block is a single tile - as ONE launch with
-// every activation resident in LDS; bit-identical to the launch-per-layer path.  Weights: a ResidualBlock's pack_h2 streams
+// every activation of a ResidualBlock resident in LDS, two blocks per CU (round 6: three / two kernels per tail, tail16_dev.h); bit-identical to the launch-per-layer path.  Weights: a ResidualBlock's pack_h2 streams
 // (RBWeights::w0h / w2h / wsch) with 1/S of its two passes (s0 = 2^-k0, s2 = 2^-k2).
 struct Chain16RB { const unsigned short *w0, *w2, *wsc; float s0, s2; };
 // MTT nets: trunk_B1 + conv_B1 -> out0; cat[up2(q), out0] -> trunk_Att1, x x5 -> trunk_B2 + conv_B2 -> out1 (accumulated)
 struct Chain16MsbdArgs {
     const unsigned short *x5; size_t x5_stride;     // [N][4][16][16][16] split-2
+    unsigned short *xb; size_t xb_stride;           // scratch, same layout: x5 * att0, handed from the attention kernel to trunk_B2's through L2
     const float *qt; float *bt, *dire;              // raw QT logits [N][64]; outputs [N][3][256], layers 0 and 1
     Chain16RB b1[3], att[2], b2[3];
     const float *head_w[2], *head_b[2];             // conv_B1, conv_B2: [9][8][2] + [2]
@@ -74,6 +75,7 @@ hipError_t launch_msbd_branch16(hipStream_t s, const Chain16MsbdArgs &a);
 // QT nets: resblock_q3 -> multi-scale pool -> resblock_q4 -> resblock_q5 + max_pool2d(2) -> resblock_q6 (8x8, fp32 direct) -> conv_q2
 struct Chain16QtArgs {
     const unsigned short *x4; size_t x4_stride;     // [N][4][16][16][16] split-2: resblock_q2's pooled output
+    float *x5;                                      // scratch [N][2][16][16][16] fp32: resblock_q3's output (the multi-scale pool reads fp32)
     float *qt;                                      // [N][64]
     Chain16RB q3, q4, q5;
     const float *d_w0, *d_w2, *d_wsc;               // resblock_q6, plain fp32 packing (pack_plain)

@@ -1,4 +1,4 @@
-// chain16_dev.h — device building blocks of the LDS-resident layer chains (chain16.hip): halo-image geometry, the K-step list of
+// chain16_dev.h — ROUND 4 form of the LDS-resident layer chains (six halo images, eight waves, one workgroup per CU; the product uses csrc/tail16_dev.h since round 6), kept for the fused-ResidualBlock prototype rbfuse_proto.hip: halo-image geometry, the K-step list of
 // pack_h2, the unrolled convolution pass, the epilogue, a ResidualBlock on LDS images.  Header so that the measurement library's
 // fused-ResidualBlock prototype (abl/rbfuse_proto.hip) builds on the same code.
 #pragma once
