@@ -140,6 +140,35 @@ __device__ __forceinline__ void t16_accumulate(const char *src, int row0, f32x4 
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// A 1x1 pass over ONE pair of source groups whose values are fp32 and not resident as an image: the B fragments - 8 channels of a pixel, both
+// fp16 terms - are split in registers from `src(group, row, x)` (16 floats of that pixel), exactly as t16_store_split would have written them
+// into an image, and fed to the same three products.  No image, no barrier: resblock_q4's shortcut over the four pairs of x6.
+template <int RW, class Src>
+__device__ __forceinline__ void t16_accumulate_1x1_f32(Src src, int row0, f32x4 (&acc)[RW], T16Pass<1, 2> &p)
+{
+    const int lane = threadIdx.x & 63, xl = lane & 15, g = lane >> 4;
+    const f16x8 w0 = p.wq[0][0], w1 = p.wq[0][1];
+    f32x4 va[RW], vb[RW];
+#pragma unroll
+    for (int m = 0; m < RW; ++m) {
+        const float *s = src(g >> 1, row0 + m, xl) + (g & 1) * 8;      // K-half = group of the pair, then the 8-channel half
+        va[m] = *reinterpret_cast<const f32x4 *>(s);
+        vb[m] = *reinterpret_cast<const f32x4 *>(s + 4);
+    }
+#pragma unroll
+    for (int m = 0; m < RW; ++m) {
+        unsigned p0, q0, p1, q1, p2, q2, p3, q3;
+        h2_split_pair(va[m].x, va[m].y, p0, q0);
+        h2_split_pair(va[m].z, va[m].w, p1, q1);
+        h2_split_pair(vb[m].x, vb[m].y, p2, q2);
+        h2_split_pair(vb[m].z, vb[m].w, p3, q3);
+        const f16x8 h0 = __builtin_bit_cast(f16x8, (u32x4){p0, p1, p2, p3}), h1 = __builtin_bit_cast(f16x8, (u32x4){q0, q1, q2, q3});
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, h0, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, h0, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, h1, acc[m], 0, 0, 0);
+    }
+}
+
 template <int RW>
 __device__ __forceinline__ void t16_zero(f32x4 (&acc)[RW])
 {
@@ -163,6 +192,7 @@ struct T16Epi {
     float *dst_f32;                     // T16_F32 / T16_POOL: output of this wave's group (LDS or global)
     unsigned short *dst_glb;            // T16_GLB: this wave's group of a global split-2 tensor
     size_t glb_stride;
+    int f32_pitch;                      // T16_F32: floats per pixel (16; 20 where a head reads the map: conflict-free 16-byte reads of consecutive pixels)
 };
 
 template <int RW, bool RES, bool GATE, int OUT>
@@ -201,7 +231,7 @@ __device__ __forceinline__ float t16_epilogue(f32x4 (&acc)[RW], int row0, const 
         } else if (OUT == T16_F32) {
 #pragma unroll
             for (int k = 0; k < 2; ++k)
-                *reinterpret_cast<f32x4 *>(e.dst_f32 + (((row0 + m + k) * 16 + xl) * 16 + g * 4)) = acc[m + k];
+                *reinterpret_cast<f32x4 *>(e.dst_f32 + (((row0 + m + k) * 16 + xl) * e.f32_pitch + g * 4)) = acc[m + k];
         } else {
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
@@ -264,29 +294,64 @@ __device__ __forceinline__ float t16_store_split(char *img, int px, int c4, f32x
     return sat_amax4(amax, v);
 }
 
-// conv_misc.hip's head_kernel on an LDS-resident fp32 map [S*S px][16] (channels 0..7): 3x3, 8 -> cout, bias, no activation
-template <int S>
-__device__ __forceinline__ void t16_head(const float *f, const float *w, const float *bias, int cout, int t, float &acc0, float &acc1)
+// conv_misc.hip's head_kernel on an LDS-resident fp32 map [S*S px][PITCH] (channels 0..7): 3x3, 8 -> cout, bias, no activation.  The
+// weights [9][8][cout] and the bias are in LDS too (`w`, `bias`: the caller staged them; every lane reads the same address - a broadcast).
+#define T16_LDS __attribute__((address_space(3)))
+// (Branch-free: a tap outside the map is computed on a clamped pixel and dropped by a select - the reference skips it, the chain of the
+// taps that count is the same fmaf sequence; with `continue` in the loops hipcc cannot hoist the LDS reads and every tap pays their latency.)
+template <int S, int PITCH>
+__device__ __forceinline__ void t16_head(const float *f_, const float *w_, const float *bias_, int cout, int t, float &acc0, float &acc1)
 {
+    const T16_LDS float *f = (const T16_LDS float *)f_, *w = (const T16_LDS float *)w_, *bias = (const T16_LDS float *)bias_;
     const int x = t % S, y = t / S;
     acc0 = bias[0];
     acc1 = cout > 1 ? bias[1] : 0.f;
+#pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
         const int yy = y + dy - 1;
-        if (yy < 0 || yy >= S) continue;
+        const bool oky = yy >= 0 && yy < S;
+#pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
             const int xx = x + dx - 1;
-            if (xx < 0 || xx >= S) continue;
-            const float *xp = f + (yy * S + xx) * 16;
-            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(xp), v1 = *reinterpret_cast<const f32x4 *>(xp + 4);
+            const bool ok = oky && xx >= 0 && xx < S;
+            const T16_LDS float *xp = f + ((oky ? yy : y) * S + (xx >= 0 && xx < S ? xx : x)) * PITCH;
+            const f32x4 v0 = *reinterpret_cast<const T16_LDS f32x4 *>(xp), v1 = *reinterpret_cast<const T16_LDS f32x4 *>(xp + 4);
             const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            const float *wp = w + (dy * 3 + dx) * 8 * cout;
+            const T16_LDS float *wp = w + (dy * 3 + dx) * 8 * cout;
+            float t0 = acc0, t1 = acc1;
+            if (cout > 1) {
+                float wv[16];
 #pragma unroll
-            for (int ci = 0; ci < 8; ++ci) {
-                acc0 = fmaf(v[ci], wp[ci * cout], acc0);
-                if (cout > 1) acc1 = fmaf(v[ci], wp[ci * cout + 1], acc1);
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 w4 = *reinterpret_cast<const T16_LDS f32x4 *>(wp + q * 4);
+                    wv[q * 4] = w4.x; wv[q * 4 + 1] = w4.y; wv[q * 4 + 2] = w4.z; wv[q * 4 + 3] = w4.w;
+                }
+#pragma unroll
+                for (int ci = 0; ci < 8; ++ci) {
+                    t0 = fmaf(v[ci], wv[ci * 2], t0);
+                    t1 = fmaf(v[ci], wv[ci * 2 + 1], t1);
+                }
+            } else {
+                const f32x4 wa = *reinterpret_cast<const T16_LDS f32x4 *>(wp), wb = *reinterpret_cast<const T16_LDS f32x4 *>(wp + 4);
+                const float wv[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+#pragma unroll
+                for (int ci = 0; ci < 8; ++ci) t0 = fmaf(v[ci], wv[ci], t0);
             }
+            acc0 = ok ? t0 : acc0;
+            acc1 = ok ? t1 : acc1;
         }
+    }
+}
+
+// Zero the halo cells of `nslots` group slots (both planes, both halves): all an image needs before its interior is written - 51 of 307
+// cells: row -1 (cells 0..17, which include (0, -1)), the shared right / left halo cell of rows 0..15, and row 16 (289..306).
+__device__ __forceinline__ void t16_clear_borders(char *p, int nslots)
+{
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    for (int i = threadIdx.x; i < nslots * 4 * 51; i += T16_THREADS) {
+        const int arr = i / 51, k = i % 51;
+        const int cell = k < 18 ? k : k < 33 ? 34 + (k - 18) * T16_PITCH : 289 + (k - 33);
+        *reinterpret_cast<u32x4 *>(p + arr * T16_HALF + cell * 16) = z;
     }
 }
 
@@ -298,46 +363,43 @@ __device__ __forceinline__ void t16_clear(char *p, int bytes)
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // ResidualBlock(64 -> 32, 3x3, 1x1 shortcut) whose 64-channel input X lives in global memory (split-2, [4][256 px][16]): trunk_B1.0 /
-// trunk_B2.0 of the MTT nets, resblock_q3 of the QT nets.  Slots: A, B = the input window, C, D = the intermediate.
-//   conv 1:   X groups 0, 1 -> A, B | K-steps 0..8 | X groups 2, 3 -> A, B (requested during the first half) | K-steps 9..17
-//   t = relu(.) -> C, D;  conv 2: 9 K-steps from C, D
-//   shortcut: X groups 0, 1 again -> C, D (requested during conv 2) | K-step 0 from C, D | K-step 1 from A, B (groups 2, 3 are still there)
-// The accumulators come back UNFINISHED (no epilogue): the caller applies the block's second epilogue in the form it needs, after a
-// barrier (every slot is free then).  `p1` = the first pass's ring, started by the caller (groups 0, 1 must already be in flight: f01).
+// trunk_B2.0 of the MTT nets, resblock_q3 of the QT nets.  All four slots A..D:
+//   conv 1:   X groups 0, 1 -> A, B and 2, 3 -> C, D (both requested by the caller at kernel start) | 18 K-steps, uninterrupted
+//   t = relu(.) -> A, B (groups 0, 1 are dead);  conv 2: 9 K-steps from A, B
+//   shortcut: X groups 0, 1 again -> A, B (requested during conv 2) | K-step 0 from A, B | K-step 1 from C, D (groups 2, 3 are still there)
+// The accumulators come back UNFINISHED (no epilogue): the caller applies the block's second epilogue in the form it needs, after the
+// closing barrier (every slot is free then).  `p1` = the first pass's ring, started by the caller.
 template <class Next>
-__device__ __forceinline__ float t16_rb64(const T16RB w, const unsigned short *x, size_t x_stride, char *slots, T16Fetch &f01,
+__device__ __forceinline__ float t16_rb64(const T16RB w, const unsigned short *x, size_t x_stride, char *slots, T16Fetch &f01, const T16Fetch &f23,
                                           f32x4 (&acc)[8], float amax, T16Pass<9, 2> &p1, Next start_next)
 {
     typedef T16Tile<2> WT;
     char *A = slots, *C = slots + 2 * T16_SLOT;
     const int ct = WT::ct(), row0 = WT::row0();
     t16_park(f01, A);
-    T16Fetch f23;
-    t16_fetch(f23, x, x_stride, 2);
+    t16_park(f23, C);
+    T16Pass<9, 2> p1b;
+    t16_wstart(p1b, w.w0 + 9 * 2 * T16_KSTEP, 2, ct);
     __syncthreads();
     t16_zero<8>(acc);
     t16_accumulate<9, 2, 8>(A, row0, acc, p1);
-    T16Pass<9, 2> p1b;
-    t16_wstart(p1b, w.w0 + 9 * 2 * T16_KSTEP, 2, ct);
-    __syncthreads();                                   // every wave is done with groups 0, 1
-    t16_park(f23, A);
-    __syncthreads();
-    t16_accumulate<9, 2, 8>(A, row0, acc, p1b);
+    t16_accumulate<9, 2, 8>(C, row0, acc, p1b);
     T16Pass<9, 2> p2;
     t16_wstart(p2, w.w2, 2, ct);
     t16_fetch(f01, x, x_stride, 0);                    // for the shortcut pass, behind conv 2
-    amax = t16_epilogue<8, false, false, T16_IMG>(acc, row0, T16Epi{w.s0, nullptr, nullptr, 0, C + ct * T16_SLOT, nullptr, nullptr, 0}, amax);   // C, D are nobody's source: no barrier before
+    __syncthreads();                                   // every wave is done with groups 0, 1: the intermediate takes their slots
+    amax = t16_epilogue<8, false, false, T16_IMG>(acc, row0, T16Epi{w.s0, nullptr, nullptr, 0, A + ct * T16_SLOT, nullptr, nullptr, 0, 16}, amax);
     __syncthreads();
     t16_zero<8>(acc);
-    t16_accumulate<9, 2, 8>(C, row0, acc, p2);
+    t16_accumulate<9, 2, 8>(A, row0, acc, p2);
     T16Pass<1, 2> p3a, p3b;
     t16_wstart(p3a, w.wsc, 2, ct);
     t16_wstart(p3b, w.wsc + 1 * 2 * T16_KSTEP, 2, ct);
     __syncthreads();                                   // every wave is done with the intermediate
-    t16_park(f01, C);
+    t16_park(f01, A);
     __syncthreads();
-    t16_accumulate<1, 2, 8>(C, row0, acc, p3a);        // ResidualBlock, Model_QBD.py:33-38: the shortcut pass follows the main pass
-    t16_accumulate<1, 2, 8>(A, row0, acc, p3b);
+    t16_accumulate<1, 2, 8>(A, row0, acc, p3a);        // ResidualBlock, Model_QBD.py:33-38: the shortcut pass follows the main pass
+    t16_accumulate<1, 2, 8>(C, row0, acc, p3b);
     start_next();
     __syncthreads();                                   // all four slots are free
     return amax;
@@ -356,7 +418,7 @@ __device__ __forceinline__ float t16_rb(const T16RB w, const char *in, char *mid
     T16Pass<1, CB_IN> p3;
     t16_wstart(p2, w.w2, NT, ct);
     if (SC) t16_wstart(p3, w.wsc, NT, ct);
-    amax = t16_epilogue<4 * NT, false, false, T16_IMG>(acc, row0, T16Epi{w.s0, nullptr, nullptr, 0, mid + ct * T16_SLOT, nullptr, nullptr, 0}, amax);   // `mid` is nobody's source: no barrier before
+    amax = t16_epilogue<4 * NT, false, false, T16_IMG>(acc, row0, T16Epi{w.s0, nullptr, nullptr, 0, mid + ct * T16_SLOT, nullptr, nullptr, 0, 16}, amax);   // `mid` is nobody's source: no barrier before
     __syncthreads();
     t16_zero<4 * NT>(acc);
     t16_accumulate<9, NT, 4 * NT>(mid, row0, acc, p2);
