@@ -72,6 +72,12 @@ __global__ __launch_bounds__(T16_THREADS, 2) void qt_rest16_kernel(QtRest16Args 
     float amax = 0.f;
     T16Pass<9, 2> pp0;
     t16_wstart(pp0, a.q4.w0, 2, ct);
+    f32x4 v0[8];                                    // pair 0 of x6 = x5 itself: its values for the window, requested before the pooling reads the same lines
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = tid + k * T16_THREADS, c4 = (i & 3) * 4, px = (i >> 2) & 255, cb = i >> 10;
+        v0[k] = *reinterpret_cast<const f32x4 *>(x5 + cb * 4096 + px * 16 + c4);
+    }
     t16_clear_borders(slots, 2);                    // the window A, B; C, D become images only as resblock_q5's intermediate
     // multi-scale pool (conv_misc.hip: multipool_concat_kernel), both groups
 #pragma unroll
@@ -110,7 +116,7 @@ __global__ __launch_bounds__(T16_THREADS, 2) void qt_rest16_kernel(QtRest16Args 
 #pragma unroll
         for (int k = 0; k < 8; ++k) {               // (group, pixel, quad of channels)
             const int i = tid + k * T16_THREADS, c4 = (i & 3) * 4, px = (i >> 2) & 255, cb = i >> 10;
-            v[k] = *reinterpret_cast<const f32x4 *>(x6_src(p, cb, px >> 4, px & 15) + c4);
+            v[k] = p == 0 ? v0[k] : *reinterpret_cast<const f32x4 *>(x6_src(p, cb, px >> 4, px & 15) + c4);
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -149,6 +155,14 @@ __global__ __launch_bounds__(T16_THREADS, 2) void qt_rest16_kernel(QtRest16Args 
     t16_clear_borders(C, 2);                        // C, D become resblock_q5's intermediate
     amax = t16_epilogue<8, false, false, T16_IMG>(acc, row0, T16Epi{a.q4.s2, nullptr, nullptr, 0, A + ct * T16_SLOT, nullptr, nullptr, 0, 16}, amax);   // x7 -> A, B
     __syncthreads();
+    // resblock_q6's and the head's weights (12.8 KB of fp32, the same for every block): requested here, parked in LDS behind resblock_q5
+    float wr0[9], wr2[3], wrs, wrh;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wr0[k] = a.d_w0[tid + k * T16_THREADS];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) wr2[k] = a.d_w2[min(tid + k * T16_THREADS, 9 * 8 * 8 - 1)];
+    wrs = a.d_wsc[tid];
+    wrh = tid < 72 ? a.head_w[tid] : a.head_b[0];
     // resblock_q5: 32 -> 32, identity shortcut, max_pool2d(2) -> fp32 [2][64][16]
     amax = t16_rb<2, 2, false>(a.q5, A, C, acc, amax, pq5, []() {});
     float *x8 = reinterpret_cast<float *>(C);       // over the dead intermediate
@@ -158,10 +172,12 @@ __global__ __launch_bounds__(T16_THREADS, 2) void qt_rest16_kernel(QtRest16Args 
     // (8) input channels of a tap are 16-byte reads; a thread runs the chains of pixels px and px + 32 of one cout side by side (same weights).
     float *D_ = reinterpret_cast<float *>(slots + 3 * T16_SLOT);       // D is dead (resblock_q5's intermediate); A, B are still the residual
     float *wd0 = D_, *wd2 = wd0 + 9 * 8 * 36, *wds = wd2 + 9 * 8 * 12, *hw = wds + 8 * 36;     // 2592 + 864 + 288 + 73 floats = 15.3 KB
-    for (int i = tid; i < 9 * 32 * 8; i += T16_THREADS) wd0[((i >> 8) * 8 + (i & 7)) * 36 + ((i >> 3) & 31)] = a.d_w0[i];      // [tap][ci][co] -> [tap][co][36]
-    for (int i = tid; i < 9 * 8 * 8; i += T16_THREADS) wd2[((i >> 6) * 8 + (i & 7)) * 12 + ((i >> 3) & 7)] = a.d_w2[i];        // [tap][ci][co] -> [tap][co][12]
-    wds[(tid & 7) * 36 + (tid >> 3)] = a.d_wsc[tid];                                                                            // [ci][co] -> [co][36]
-    if (tid < 73) hw[tid] = tid < 72 ? a.head_w[tid] : a.head_b[0];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { const int i = tid + k * T16_THREADS; wd0[((i >> 8) * 8 + (i & 7)) * 36 + ((i >> 3) & 31)] = wr0[k]; }      // [tap][ci][co] -> [tap][co][36]
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const int i = tid + k * T16_THREADS; if (i < 9 * 8 * 8) wd2[((i >> 6) * 8 + (i & 7)) * 12 + ((i >> 3) & 7)] = wr2[k]; }   // [tap][ci][co] -> [tap][co][12]
+    wds[(tid & 7) * 36 + (tid >> 3)] = wrs;                                                                                    // [ci][co] -> [co][36]
+    if (tid < 73) hw[tid] = wrh;
     __syncthreads();
     float *t8 = reinterpret_cast<float *>(A), *y8 = t8 + 1024;     // [64][16] each, channels 8..15 zero (A: the residual is dead now)
     {

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run ON THE GPU BOX: PMC passes (counters only) over a short bench.py run, summarised for the rbfuse32 kernels -> gpurun_out/pmc_rbfuse32/   (rbfuse32, chain16, stems, post-processing: the kernels next to the big convolutions)
 set -u
-OUT=$PWD/gpurun_out/pmc_rbfuse32
+OUT=$PWD/gpurun_out/pmc_small
 mkdir -p $OUT
 export TMPDIR=/tmp
 CMD="python3 $PWD/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-extras"
@@ -22,7 +22,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if not any(t in k for t in ("rbfuse32", "branch16", "tail16", "stem_mfma", "postprocess_kernel", "conv_h2_kernel<3, 3, 2")): continue
+        if not any(t in k for t in ("rbfuse32", "branch16", "att16", "qt_rest16", "q3_rb64", "stem_mfma", "postprocess_kernel", "conv_h2_kernel<3, 3, 2")): continue
         k = k.replace("pmp::(anonymous namespace)::", "").replace("void ", "").split("(")[0]
         a = acc[k][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
 for k in sorted(acc):
