@@ -163,7 +163,7 @@ struct Graph {
             if (consume) release(x_in);
             return y;
         }
-        if (!gate && consume && fused32(x_in, r) && (pool ? out_f32 : !out_f32) && (!pool || r.cout_pad == 16)) return rb_fused32(x_in, name, r, pool);
+        if (!gate && consume && fused32(x_in, r, pool) && (pool ? out_f32 : !out_f32)) return rb_fused32(x_in, name, r, pool);
         Act x = to_conv_input(x_in);
         const bool converted = x.p != x_in.p || x.off != x_in.off;
         if (converted && consume) release(x_in);
@@ -204,10 +204,13 @@ struct Graph {
 
     // rbfuse32.hip (f16x3): a ResidualBlock with <= 32 output channels at 32x32 as ONE launch, the intermediate in LDS; bit-identical to rb().
     // pool_f32: + 2x2 max-pool, plain fp32 output (trunk_B3.2, read by the head kernel).
-    bool fused32(const Act &x, const RBWeights &r) const
+    // Exactly the three instantiations launch_rbfuse32 has (the predicate used to admit (16, 16) without pool and (32, 16) with
+    // pool, which the launcher rejects - no block of the four nets has those shapes, but such a block would have failed the call instead
+    // of taking the launch-per-layer path): (cin, cout, pool) = (32, 16, no) trunk_B3.1, (16, 16, yes) trunk_B3.2, (16, 32, no) trunk_Att2.0.
+    bool fused32(const Act &x, const RBWeights &r, bool pool) const
     {
         return h2() && c->fuse32 && x.H == 32 && x.W == 32 && x.split && r.w0h && r.has_sc && !r.direct && r.k == 3 &&
-               ((r.cin_pad == 32 && r.cout_pad == 16) || (r.cin_pad == 16 && r.cout_pad == 16) || (r.cin_pad == 16 && r.cout_pad == 32));
+               ((r.cin_pad == 32 && r.cout_pad == 16 && !pool) || (r.cin_pad == 16 && r.cout_pad == 16 && pool) || (r.cin_pad == 16 && r.cout_pad == 32 && !pool));
     }
     // trunk_Att2.0 with its input built from the logits inside the kernel (no att_input launch, no input tensor)
     Act rb_fused32_att(const std::string &name, const float *q, const float *bt, const float *dire, int layer, int S)
