@@ -293,11 +293,11 @@ int pmp_debug_set_conv_variant(int variant);
 int pmp_debug_set_winograd(pmp_ctx *ctx, int on);
 
 /* ---- test / A-B hook (f16x3 datapath, per context): launch fusion.  on = 1 (default): (a) the 16x16-resolution tails of the nets - trunk_B1/B2 +
- *      heads + attention 1 of the MTT nets, resblock_q3 .. conv_q2 of the QT nets - run as ONE launch per net with the activations
- *      resident in LDS (chain16.hip), and (b) the ResidualBlocks with <= 32 output channels at 32x32 - trunk_B3.1, trunk_B3.2 (+ pool),
+ *      heads + attention 1 of the MTT nets, resblock_q3 .. conv_q2 of the QT nets - run as two (QT) / three (MTT) launches per net with the activations of
+ *      a ResidualBlock resident in LDS, two blocks per CU (chain16.hip), and (b) the ResidualBlocks with <= 32 output channels at 32x32 - trunk_B3.1, trunk_B3.2 (+ pool),
  *      trunk_Att2.0 of the MTT nets - as one launch per block with the intermediate in LDS (rbfuse32.hip).  on = 0: launch per layer, as the
  *      other two datapaths always do; on = 2: (a) only; on = 3: (b) only.  Results are BIT-IDENTICAL in all four settings
- *      (tests/test_gpu_parity.py::test_fused_16x16_tails_are_bit_identical); only the launch count (68 -> 38 per luma pass) and the time
+ *      (tests/test_gpu_parity.py::test_fused_16x16_tails_are_bit_identical); only the launch count (68 -> 40 per luma pass) and the time
  *      differ.  Settles the calls in flight first. ---- */
 int pmp_debug_set_fusion(pmp_ctx *ctx, int on);
 

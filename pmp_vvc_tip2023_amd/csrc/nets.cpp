@@ -284,7 +284,7 @@ int forward_q(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, con
     Act x2 = g.stem(luma, false, by, bu, bv, nullptr);
     Act x3 = g.rb(x2, "resblock_q1", luma);            // luma: + max_pool2d(2); chroma: no pool (:179)
     Act x4 = g.rb(x3, "resblock_q2", true);
-    if (g.fused16()) {   // q3 .. conv_q2 at 16x16 / 8x8: one launch, one workgroup per block, activations in LDS (chain16.hip)
+    if (g.fused16()) {   // q3 .. conv_q2 at 16x16 / 8x8: two launches, four waves per block and two blocks per CU, activations in LDS (chain16.hip)
         Chain16QtArgs a{};
         double flops = 0;
         auto q6 = w.rb.find("resblock_q6");
@@ -330,7 +330,7 @@ int forward_msbd(pmp_ctx *c, bool luma, const NetWeights &w, const uint8_t *by, 
     for (int i = 1; i < 3; ++i) x = g.rb(x, "trunk_M2." + std::to_string(i));
     Act x5 = g.rb(x, "trunk_M2.3", true);
     Act b{};
-    if (g.fused16()) {   // B1 + conv_B1, attention 1, B2 + conv_B2 at 16x16: one launch (chain16.hip)
+    if (g.fused16()) {   // B1 + conv_B1, attention 1, B2 + conv_B2 at 16x16: three launches (chain16.hip)
         Chain16MsbdArgs a{};
         double flops = 2.0 * 2 * n * 256 * 72.0 * 2;
         bool ok = true;

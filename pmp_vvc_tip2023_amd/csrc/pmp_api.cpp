@@ -387,7 +387,7 @@ extern "C" {
 const char *pmp_version(void)
 {
     if (const char *v = abl_version()) return v;     // a measurement build says so
-    return "pmp-hip 0.5 (gfx950; f16x3 default with calibrated activation scales, bf16x6 and fp32 MFMA datapaths)";
+    return "pmp-hip 0.6 (gfx950; f16x3 default with calibrated activation scales, bf16x6 and fp32 MFMA datapaths)";
 }
 
 const char *pmp_last_error(const pmp_ctx *ctx) { return ctx ? ctx->err.c_str() : global_err(); }

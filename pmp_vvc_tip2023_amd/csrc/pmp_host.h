@@ -133,7 +133,7 @@ struct pmp_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     int chunk = 4096;   // blocks per pass: the 16x16-resolution layers need >= 4096 tiles to fill 256 CUs x 3 workgroups evenly (+2.5 % over 1024)
     int precision = 2;                     // 0: fp32 MFMA, 1: bf16x6 split, 2: f16x3 split (default; both splits fp32-equivalent)
-    int fuse16 = 1;                        // f16x3: run the 16x16-resolution tails as one launch per net (chain16.hip); 0 = launch per layer (pmp_debug_set_fusion: A/B and the bit-identity tests)
+    int fuse16 = 1;                        // f16x3: run the 16x16-resolution tails LDS-resident (chain16.hip: two / three launches per net); 0 = launch per layer (pmp_debug_set_fusion: A/B and the bit-identity tests)
     int act_scales = 1;                    // f16x3: use the MTT nets' calibrated activation scales (NetWeights::act_exp); 0 = exponents of zero (pmp_debug_set_activation_scales: the range-guard tests)
     int fuse32 = 1;                        // f16x3: trunk_B3.1 / B3.2 / Att2.0 (32x32, <= 32 output channels) as one launch per ResidualBlock (rbfuse32.hip); same hook
     std::string err;

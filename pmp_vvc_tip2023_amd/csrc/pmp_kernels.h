@@ -55,8 +55,8 @@ hipError_t launch_conv_h2(hipStream_t s, const ConvX6Args &a);
 hipError_t launch_f32_to_split2(hipStream_t s, const float *x, unsigned short *out, size_t n, size_t plane_stride, unsigned *sat = nullptr);
 hipError_t launch_split2_to_f32(hipStream_t s, const unsigned short *x, float *out, size_t n, size_t plane_stride);
 
-// ------------------------------------------------------------------------------------------------ 16x16 tails, one workgroup per block
-// chain16.hip (f16x3 datapath): the layers of a net that run at 16x16 resolution - where a block is a single tile - as ONE launch with
+// ------------------------------------------------------------------------------------------------ 16x16 tails, LDS-resident
+// chain16.hip (f16x3 datapath): the layers of a net that run at 16x16 resolution - where a block is a single tile - with
 // every activation of a ResidualBlock resident in LDS, two blocks per CU (round 6: three / two kernels per tail, tail16_dev.h); bit-identical to the launch-per-layer path.  Weights: a ResidualBlock's pack_h2 streams
 // (RBWeights::w0h / w2h / wsch) with 1/S of its two passes (s0 = 2^-k0, s2 = 2^-k2).
 struct Chain16RB { const unsigned short *w0, *w2, *wsc; float s0, s2; };

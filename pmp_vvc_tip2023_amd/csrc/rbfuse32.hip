@@ -12,7 +12,7 @@
 //
 // Traffic per block and ResidualBlock: 1.56 x input + output instead of 2 x input + 2 x intermediate + output (B3.1: 270 KB for 457,
 // B3.2: 118 for 276, Att2.0: 131 for 588 - its input, three channels made of logits, is built in the kernel and never exists in HBM).  BIT-IDENTICAL to the launch-per-layer path (tests/test_gpu_parity.py): the same pack_h2 weight
-// streams in the same K-step order (chain16_dev.h's list, restated for these image widths), the same three products per K-step into the
+// streams in the same K-step order (tail16_dev.h's list, restated for these image widths), the same three products per K-step into the
 // same fp32 accumulators (x0*w1, x0*w0, x1*w0), the main pass before the shortcut pass, the epilogue arithmetic of conv_f16x3.hip
 // (x 1/S, ReLU, range-flag maximum, pool, two-term split with the clamp).  A value of t that two tiles both compute is the same number
 // in both.  LDS 46-72 KB: two workgroups of eight waves per CU.
@@ -38,7 +38,7 @@ constexpr int RF_TPLN = 2 * RF_THH, RF_TSLOT = 2 * RF_TPLN;
 constexpr int RF_GRID = 512;                                 // persistent workgroups: 2 per CU x 256 CUs
 constexpr int RF_NT1 = (RF_TW * RF_TW + 15) / 16;            // 21 pixel columns-of-16 cover the 18x18 region of the first convolution
 
-// pack_h2's K-step list (pack.cpp; chain16_dev.h: c16_step_off) for an image of width IMW and group slots of SLOT bytes:
+// pack_h2's K-step list (pack.cpp; tail16_dev.h: t16_step_off) for an image of width IMW and group slots of SLOT bytes:
 // byte offset (group + tap) of K-half `half` of step `st`.  T = 1: the offset of the tap is in the caller's pixel base.
 template <int T, int CB, int IMW, int SLOT>
 __device__ __forceinline__ constexpr int rf_step_off(int st, int half)
