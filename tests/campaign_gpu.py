@@ -41,7 +41,7 @@ def test_full_size_parity(eng, comp, qp):
     y, u, v = synth.recipe_r_blocks(N, 5000 + qp + (11 if not luma else 0))
     wq, _ = W.load_net_weights(comp + "_Q", qp)
     if MTT_WEIGHTS == "trained_like":
-        wbd, src = trained_like.msbd_weights(comp, qp), "trained-like (synth.py)"
+        wbd, src = trained_like.msbd_weights(comp, qp), "trained-like (tools/trained_like.py)"
         eng.load(comp, qp, msbd_weights=wbd)
         print("\n       trained-like MTT weights: activation exponents %s" % eng.activation_report(comp, qp)["exps"], flush=True)
     else:
