@@ -668,6 +668,32 @@ def test_postprocess_value_range_bit_exact_vs_reference_golden(eng):
         assert np.array_equal(r[:, 512:576].reshape(n, 8, 8), q8g) and np.array_equal(r[:, 576:].view(np.int8).reshape(n, 3, 16, 16), dout)
 
 
+def test_postprocess_random_bit_patterns_vs_oracle(eng, oracle_lib):
+    """"Every float32 bit pattern" taken literally: 3000 triples per chroma factor whose logits are raw random bits (NaNs with payloads,
+    denormals, 1e38s, both zeros - a third of them pure noise, the rest valid partitions with 5..30 % of their cells replaced) against the
+    oracle, which G3b's "bits" triples and tests/test_oracle_postproc.py pin on the reference for exactly this kind of input."""
+    from pmp_vvc_tip2023_amd import synth
+    for cf, comp in ((1, "Luma"), (2, "Chroma")):
+        rng = np.random.default_rng(9000 + cf)
+        n = 3000
+
+        def bits(shape):
+            return rng.integers(0, 2 ** 32, size=shape, dtype=np.uint64).astype(np.uint32).view(np.float32)
+        qt, bt, dire = synth.random_partition_batch(n, 777 + cf, cf, 0.2)
+        qt = (qt + rng.normal(0, 0.25, qt.shape)).astype(np.float32)
+        frac = rng.choice([0.05, 0.1, 0.3, 1.0], size=n, p=[0.25, 0.25, 0.17, 0.33])
+        for arr in (qt, bt, dire):
+            m = rng.random(arr.shape) < frac.reshape((n,) + (1,) * (arr.ndim - 1))
+            arr[m] = bits(int(m.sum()))
+        h, v, q8, d8 = eng.post_process(qt, bt, dire, comp)
+        with np.errstate(invalid="ignore"):
+            fixed = oracle_lib.eli_structural_error(qt).reshape(-1, 8, 8)
+            oh, ov, od, _ = oracle_lib.map_to_partition(fixed, bt, dire, cf)
+            assert np.array_equal(q8, np.nan_to_num(fixed, nan=0.0).astype(np.uint8))
+        assert np.array_equal(h, oh) and np.array_equal(v, ov) and np.array_equal(d8, od)
+        assert np.isnan(fixed).any() and not np.isfinite(bt).all()
+
+
 def test_fused_path_on_overflowing_nets_matches_the_oracle_on_its_own_logits(eng, g1, oracle_lib):
     """Logits that really come out of the nets beyond every sane range: MTT weights whose stem is scaled by 2^17 with the activation scales
     off (f16x3 under PMP_SAT_IGNORE: clamped activations, wrong but finite logits), and head biases of +inf / NaN / -inf (every datapath:

@@ -102,3 +102,26 @@ def test_oracle_against_live_reference(oracle_lib):
         for i in range(len(qt)):
             rh, rv, rd = M2P.map_to_parititon(qt[i], bt[i], dire[i], cf)
             assert np.array_equal(rh, h[i]) and np.array_equal(rv, v[i]) and np.array_equal(rd, d[i]), (seed, cf, i)
+    # ... and on raw random bit patterns (round 6: the kernel is tested against the oracle on these): the QT fix included
+    import warnings
+    import torch
+    _, Met, _, _ = R.load()
+    rng = np.random.default_rng(seed)
+    for cf in (1, 2):
+        for k in range(12):
+            if k % 2:
+                ql, b, d = (rng.integers(0, 2 ** 32, size=sh, dtype=np.uint64).astype(np.uint32).view(np.float32) for sh in ((8, 8), (3, 16, 16), (3, 16, 16)))
+            else:
+                q, b, d = synth.random_partition_maps(rng, cf)
+                ql = (q + rng.normal(0, 0.2, q.shape)).astype(np.float32)
+                for arr in (ql, b, d):
+                    m = rng.random(arr.shape) < 0.15
+                    arr[m] = rng.integers(0, 2 ** 32, size=int(m.sum()), dtype=np.uint64).astype(np.uint32).view(np.float32)
+            with warnings.catch_warnings(), torch.no_grad():
+                warnings.simplefilter("ignore")
+                fixed = Met.eli_structual_error(torch.from_numpy(ql[None, None].copy())).numpy()[0, 0]
+                rh, rv, rd = M2P.map_to_parititon(fixed, b, d, cf)
+            of = oracle_lib.eli_structural_error(ql[None]).reshape(8, 8)
+            oh, ov, od, _ = oracle_lib.map_to_partition(of[None], b[None], d[None], cf)
+            assert np.array_equal(of, fixed, equal_nan=True), (seed, cf, k)
+            assert np.array_equal(rh, oh[0]) and np.array_equal(rv, ov[0]) and np.array_equal(rd, od[0]), (seed, cf, k)

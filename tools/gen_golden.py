@@ -260,7 +260,8 @@ def g3b_inputs(cf, seed):
       scale      the whole triple's bt multiplied so that its largest value is X (s = -1: negated)
       direscale  dire * X  (th_round keeps the structure, the float32 error sums carry the magnitude)
       qtlogit    QT logits: cells of depth >= 1 pushed to +1e4, depth-0 cells to -1e4 (clamp(round(.), 0, 3), Metrics.py:632)
-    and for NaN, +inf, -inf: sprinkled into bt, into dire, into the QT logits (single cells, 2x2 windows, whole quadrants, everything)."""
+    and for NaN, +inf, -inf: sprinkled into bt, into dire, into the QT logits (single cells, 2x2 windows, whole quadrants, everything);
+    and raw random bit patterns ("bits")."""
     rng = np.random.default_rng(seed)
     qs, bs, ds, tags = [], [], [], []
 
@@ -319,6 +320,19 @@ def g3b_inputs(cf, seed):
             q, b, d = base(); add("nf_bt", q, np.full_like(b, val), d)
             q, b, d = base(); add("nf_dire", q, b, np.full_like(d, val))
             q, b, d = base(); add("nf_all", np.full_like(q, val), np.full_like(b, val), np.full_like(d, val))
+        # raw random BIT PATTERNS (every float32 class at once: NaNs with payloads, denormals, huge, tiny, both zeros): 24 triples of pure
+        # random bits, 16 valid partitions with 10 % / 20 % of their cells replaced by random bits
+        def bits(shape):
+            return rng.integers(0, 2 ** 32, size=shape, dtype=np.uint64).astype(np.uint32).view(np.float32)
+        for _ in range(24):
+            add("bits", bits((8, 8)), bits((3, 16, 16)), bits((3, 16, 16)))
+        for k in range(16):
+            q, b, d = base()
+            f = 0.1 * (1 + k % 2)
+            for arr in (q, b, d):
+                m = rng.random(arr.shape) < f
+                arr[m] = bits(int(m.sum()))
+            add("bits", q, b, d)
     return np.stack(qs), np.stack(bs), np.stack(ds), np.array(tags)
 
 
