@@ -747,6 +747,19 @@ def test_block_cutter_1080p_vs_oracle(eng, oracle_lib):
     assert e[0].shape == (0, 68, 68)
 
 
+def test_block_cutter_8k_frame_vs_oracle(eng, oracle_lib):
+    """The largest picture a VVC level admits here: one 7680x4320 frame, 8040 blocks, 10-bit (the half-even reduction on 33 M samples) and
+    8-bit, host-pointer seam - byte for byte the oracle's cutter (Inference_QBD.py:104-149)."""
+    rng = np.random.default_rng(8)
+    y = rng.integers(0, 1024, size=(1, 4320, 7680), dtype=np.uint16)
+    u = rng.integers(0, 1024, size=(1, 2160, 3840), dtype=np.uint16)
+    v = rng.integers(0, 1024, size=(1, 2160, 3840), dtype=np.uint16)
+    for bd, (a, b, c) in ((10, (y, u, v)), (8, tuple((t & 255).astype(np.uint8) for t in (y, u, v)))):
+        by, bu, bv = eng.output_block_yuv(a, b, c, bd)
+        oy, ou, ov = oracle_lib.cut_blocks(a, b, c, bd)
+        assert by.shape == (120 * 67, 68, 68) and np.array_equal(by, oy) and np.array_equal(bu, ou) and np.array_equal(bv, ov), bd
+
+
 # ------------------------------------------------------------------------------------------------ full path, full size
 def test_config2_full_batch_properties(eng, oracle_lib):
     """BASELINE.json configs[1] size (1024 luma CTUs = 4096 blocks, QP22: one bench.py step), device-resident fused path:
