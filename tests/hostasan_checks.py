@@ -149,6 +149,22 @@ def main():
         assert (nid.value, qp.value, nt.value) == (_lib.NET_IDS[man["net"]], man["qp"], len(tens))
         ref = sum(float(np.sum(t.astype(np.float64))) for t in tens.values())
         assert abs(cs.value - ref) <= 1e-6 * max(1.0, abs(ref)) and nfl.value == sum(t.size for t in tens.values())
+    # the tensor fingerprint (round 6: what ties a manifest's act_exp to its nets) under the sanitizers, against the numpy statement of it
+    man, tens = W.load_pmpw(os.path.join(wdir, "Chroma_Q_27.pmpw"))
+    names = list(tens)[::-1]
+    descs = (_lib.TensorDesc * len(names))()
+    chunks, off = [], 0
+    for i, k in enumerate(names):
+        a = np.ascontiguousarray(tens[k], np.float32)
+        descs[i].name = k.encode(); descs[i].ndim = a.ndim
+        for j, dsz in enumerate(a.shape):
+            descs[i].shape[j] = dsz
+        descs[i].offset = off
+        chunks.append(a.reshape(-1)); off += a.size
+    blob = np.concatenate(chunks)
+    fp = C.c_uint64()
+    assert lib.pmp_fingerprint_tensors(blob.ctypes.data_as(C.c_void_p), descs, len(names), C.byref(fp)) == 0 and fp.value == W.fingerprint(tens)
+    assert lib.pmp_fingerprint_tensors(None, descs, len(names), C.byref(fp)) == -1 and lib.pmp_fingerprint_tensors(blob.ctypes.data_as(C.c_void_p), descs, 0, C.byref(fp)) == -1
     good = open(os.path.join(wdir, "Luma_Q_22.pmpw"), "rb").read()
     jl = int.from_bytes(good[6:10], "little")
     cases = {"empty": b"", "magic": b"PMPW2\n" + good[6:], "cut_manifest": good[:10 + jl // 2], "cut_payload": good[:10 + jl + 100],
