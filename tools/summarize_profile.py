@@ -17,7 +17,7 @@ def short(name):
     if m:
         return "conv_x6_kernel<%s, %s, %s>" % m.groups()[1:]
     m = re.search(r"(conv_h2_kernel)<(\d+), ?(\d+), ?(\d+), ?(\w+)(?:, ?(\d+), ?(\w+))?(?:, ?(\w+))?", name)
-    if m:   # product: <KH, KW, NT, SC[, LEAN]>; notebook (csrc/abl): <KH, KW, NT, SC, ABL, LEAN, W8>.  LEAN = the 168-VGPR three-workgroups-per-CU form
+    if m:   # product: <KH, KW, NT, SC[, LEAN]>; notebook (tools/abl): <KH, KW, NT, SC, ABL, LEAN, W8>.  LEAN = the 168-VGPR three-workgroups-per-CU form
         lean = m.group(7) if m.group(6) is not None else m.group(8)
         return "conv_h2_kernel<%s, %s, %s, sc=%s>%s" % (m.group(2), m.group(3), m.group(4), m.group(5), " 3wg" if lean in ("true", "1") else "")
     name = name.replace("void ", "").replace("pmp::", "").replace("(anonymous namespace)::", "")
