@@ -209,7 +209,7 @@ def test_product_library_has_no_ablation_knobs(lib):
         src = open(os.path.join(csrc, f)).read()
         assert "PMP_ABLATION" not in src and "g_conv_variant" not in src and "s_memtime" not in src, f
         assert not re.search(r"\bABL\b", src), f
-    assert os.path.getsize(_lib.LIB_PATH) < 2.3e6          # 2.78 MB with the notebook inside (round 2); 2.0 MB + the fused 16x16 tails (chain16.hip, round 4)
+    assert os.path.getsize(_lib.LIB_PATH) < 2.45e6         # 2.78 MB with the notebook inside (round 2); 2.0 MB + the fused 16x16 tails (round 4); 2.25 MB with five tail kernels (round 6)
 
 
 def test_pmpw_container_reader_matches_python(lib, tmp_path):
